@@ -1,0 +1,232 @@
+"""avrecode-ms_amd: MI355X-native arithmetic re-encoder for H.264 CABAC bin streams.
+
+Python is plumbing here: it builds and loads the C-ABI shared library
+(``libavrecode_hip.so``, declared in ``include/avrecode_ms_amd.h``) and offers thin
+helpers that hand torch device memory to it.  All coding happens in the HIP kernels
+(``csrc/avr_kernels.hip``); there is no CPU coding path in this package -- if the
+library is missing or no GPU is visible the calls raise.
+
+Reference surface mirrored (pbluc/avrecode-ms, /root/reference):
+  * ``Batch``  -- deferred form of ``cabac::encoder`` (cabac_code.h:26-82, driven from
+    recode.cpp:1442-1481) and ``recoded_code::encoder`` (recode.cpp:1270, 1075-1103).
+  * ``drop_stop_byte`` / ``tail_patch`` -- recode.cpp:1508-1512 and :1354-1360.
+
+The directory name contains a hyphen (it follows the reference's repository name);
+``import avrecode_ms_amd`` works through the alias module at the repository root.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libavrecode_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avrecode_ms_amd.h")
+
+KIND_CABAC, KIND_RANGE = 0, 1
+SEL_BYPASS, SEL_TERMINATE = 1024, 1025
+SLICE_OK, SLICE_ZERO_PROB, SLICE_OVERFLOW, SLICE_BAD_RECORD = 0, 1, 2, 3
+
+_SOURCES = ["avr_kernels.hip", "avr_api.cpp"]
+_DEPS = _SOURCES + ["avr_coder.h", "avr_internal.h", "avr_synth.h", "avr_tables.h"]
+
+
+class AvrError(RuntimeError):
+    """Raised for every negative return code of the C ABI (message = avr_last_error())."""
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP kernels and the C ABI for gfx950 into libavrecode_hip.so (in-tree)."""
+    deps = [os.path.join(_CSRC, d) for d in _DEPS] + [HEADER_PATH]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        if os.path.exists(LIB_PATH):      # GPU box without a compiler in PATH: use the shipped build
+            return LIB_PATH
+        raise AvrError("hipcc not found and no prebuilt libavrecode_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-o", LIB_PATH + ".tmp"] + [os.path.join(_CSRC, s) for s in _SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+class SynthConfig(ctypes.Structure):
+    _fields_ = [("workload", c_int), ("scale_permille", c_uint32), ("seed", c_uint64),
+                ("first_slice", c_uint64), ("n_states", c_uint32)]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/avrecode_ms_amd.h declares
+_u8p, _u16p, _u32p, _u64p, _i32p = (POINTER(c_uint8), POINTER(c_uint16), POINTER(c_uint32),
+                                    POINTER(c_uint64), POINTER(c_int32))
+SIGNATURES = {
+    "avr_last_error": (c_char_p, []),
+    "avr_version": (c_char_p, []),
+    "avr_device_count": (c_int, []),
+    "avr_cabac_lps_range_table": (_u8p, []),
+    "avr_cabac_mlps_state_table": (_u8p, []),
+    "avr_batch_create": (c_void_p, [c_int, c_size_t, c_size_t]),
+    "avr_batch_destroy": (None, [c_void_p]),
+    "avr_batch_reset": (c_int, [c_void_p]),
+    "avr_batch_add_slice_cabac": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
+    "avr_batch_add_slice_range": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "avr_batch_run": (c_int, [c_void_p]),
+    "avr_batch_get": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
+    "avr_batch_get_states": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]),
+    "avr_batch_timings": (c_int, [c_void_p, POINTER(c_float)]),
+    "avr_pack_tiles_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                      c_void_p, c_void_p]),
+    "avr_cabac_encode_tiles_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                              c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "avr_range_encode_tiles_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "avr_cabac_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                               c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "avr_range_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    "avr_synth_config_init": (c_int, [POINTER(SynthConfig), c_int, c_uint32, c_uint64]),
+    "avr_synth_count_host": (c_int, [POINTER(SynthConfig), c_int, c_size_t, c_void_p]),
+    "avr_synth_generate_host": (c_int, [POINTER(SynthConfig), c_int, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "avr_synth_count_device": (c_int, [c_int, c_void_p, POINTER(SynthConfig), c_int, c_size_t, c_void_p]),
+    "avr_synth_generate_tiles_device": (c_int, [c_int, c_void_p, POINTER(SynthConfig), c_int, c_size_t, c_void_p,
+                                                c_void_p, c_void_p, c_void_p]),
+    "avr_drop_stop_byte": (c_size_t, [c_void_p, c_size_t]),
+    "avr_tail_patch": (c_size_t, [c_void_p, c_size_t, c_int, c_uint8]),
+}
+
+
+def lib():
+    """Load libavrecode_hip.so (building it first if a compiler is present). Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build_native()
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as exc:
+            raise AvrError(f"cannot load the HIP extension {LIB_PATH}: {exc}") from exc
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError = a declared symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def _check(rc: int) -> int:
+    if rc < 0:
+        raise AvrError(f"avr error {rc}: {lib().avr_last_error().decode()}")
+    return rc
+
+
+def device_count() -> int:
+    return lib().avr_device_count()
+
+
+def cabac_tables():
+    """(lps_range[512], mlps_state[256]) in the layout cabac_code.h:11-12 indexes."""
+    L = lib()
+    return (bytes(L.avr_cabac_lps_range_table()[:512]), bytes(L.avr_cabac_mlps_state_table()[:256]))
+
+
+def drop_stop_byte(buf: bytes) -> bytes:
+    """decompressor::cabac_decoder::finish (recode.cpp:1508-1512)."""
+    a = (c_uint8 * max(len(buf), 1)).from_buffer_copy(buf.ljust(1, b"\0"))
+    return bytes(buf[:lib().avr_drop_stop_byte(a, len(buf))])
+
+
+def tail_patch(buf: bytes, length_parity: int, last_byte: int) -> bytes:
+    """decompressor::run block patch (recode.cpp:1354-1360)."""
+    a = (c_uint8 * (len(buf) + 1))()
+    a[:len(buf)] = buf
+    n = lib().avr_tail_patch(a, len(buf), length_parity, last_byte)
+    return bytes(a[:n])
+
+
+def make_cabac_records(bins, sels):
+    """uint16 K1 records from bin values and selectors (numpy arrays or sequences)."""
+    import numpy as np
+    return (np.asarray(bins, dtype=np.uint16) & 1) | (np.asarray(sels, dtype=np.uint16) << 1)
+
+
+def make_range_records(bins, pos, neg):
+    """uint16 K2 records from bin values and the {pos,neg} estimator of each bin."""
+    import numpy as np
+    return ((np.asarray(bins, dtype=np.uint16) & 1) | (np.asarray(pos, dtype=np.uint16) << 1)
+            | (np.asarray(neg, dtype=np.uint16) << 8))
+
+
+class Batch:
+    """Host-memory batch: add slices, run() on the GPU, get() the coded bytes.
+
+    Mirrors how the reference's drivers use their coder objects: one encoder per slice
+    (recode.cpp:1270, 1525), results read after all decoding (recode.cpp:1131, 1352-1363).
+    """
+
+    def __init__(self, device: int = 0, max_slices: int = 1024, max_bins: int = 1 << 24):
+        self._L = lib()
+        self._h = self._L.avr_batch_create(device, max_slices, max_bins)
+        if not self._h:
+            raise AvrError(self._L.avr_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._L.avr_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        _check(self._L.avr_batch_reset(self._h))
+
+    def add_slice_cabac(self, recs, init_states) -> int:
+        import numpy as np
+        r = np.ascontiguousarray(recs, dtype=np.uint16)
+        s = np.ascontiguousarray(init_states, dtype=np.uint8)
+        return _check(self._L.avr_batch_add_slice_cabac(self._h, r.ctypes.data, r.size, s.ctypes.data, s.size))
+
+    def add_slice_range(self, recs) -> int:
+        import numpy as np
+        r = np.ascontiguousarray(recs, dtype=np.uint16)
+        return _check(self._L.avr_batch_add_slice_range(self._h, r.ctypes.data, r.size))
+
+    def run(self):
+        _check(self._L.avr_batch_run(self._h))
+
+    def get(self, i: int):
+        """(bytes, status) of slice i."""
+        p, n, st = c_void_p(), c_size_t(), c_int()
+        _check(self._L.avr_batch_get(self._h, i, ctypes.byref(p), ctypes.byref(n), ctypes.byref(st)))
+        return (ctypes.string_at(p.value, n.value) if n.value else b""), st.value
+
+    def get_states(self, i: int) -> bytes:
+        p, n = c_void_p(), c_size_t()
+        _check(self._L.avr_batch_get_states(self._h, i, ctypes.byref(p), ctypes.byref(n)))
+        return ctypes.string_at(p.value, n.value) if n.value else b""
+
+    def timings(self):
+        ms = (c_float * 4)()
+        _check(self._L.avr_batch_timings(self._h, ms))
+        return dict(zip(("h2d_ms", "pack_ms", "encode_ms", "d2h_ms"), list(ms)))
+
+
+from .device import DeviceWorkload, encode_tiles, plan_tiles, synth_config  # noqa: E402  (torch-backed helpers)
+
+__all__ = ["AvrError", "Batch", "DeviceWorkload", "KIND_CABAC", "KIND_RANGE", "SEL_BYPASS", "SEL_TERMINATE",
+           "build_native", "cabac_tables", "device_count", "drop_stop_byte", "encode_tiles", "lib",
+           "make_cabac_records", "make_range_records", "plan_tiles", "synth_config", "tail_patch"]

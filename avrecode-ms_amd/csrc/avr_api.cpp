@@ -1,0 +1,474 @@
+// C ABI of the MI355X arithmetic re-encode path (include/avrecode_ms_amd.h).
+//
+// The batch object is the build's counterpart of the reference's per-slice coder objects
+// (compressor::cabac_decoder::encoder, recode.cpp:1270; decompressor::cabac_decoder::
+// cabac_encoder, recode.cpp:1525): the hook adapter records bins, a batch codes them.
+// There is no CPU coding path in this library: without a HIP device every run fails with
+// AVR_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "avr_internal.h"
+#include "avr_synth.h"
+#include "avr_tables.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    return fail(AVR_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define AVR_HIP(call)                                            \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);        \
+    } while (0)
+
+constexpr avr::CabacTables kTables = avr::make_cabac_tables();
+
+int select_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(AVR_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU coding path");
+    if (device < 0 || device >= n) return fail(AVR_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    AVR_HIP(hipSetDevice(device));
+    return AVR_OK;
+}
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;       // elements
+    int reserve(size_t n) {
+        if (n <= cap) return AVR_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
+        if (e != hipSuccess) return fail(AVR_ERR_NOMEM, "hipMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return AVR_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <class T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return AVR_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(AVR_ERR_NOMEM, "hipHostMalloc(%zu bytes): %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return AVR_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// Host-side plan shared by the batch API and tests: process slices longest first, 64 per tile.
+void plan_tiles(const std::vector<uint32_t> &n_bins, std::vector<uint32_t> &order, std::vector<uint64_t> &tile_off) {
+    const size_t n = n_bins.size();
+    order.resize(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return n_bins[a] > n_bins[b]; });
+    const size_t n_tiles = (n + 63) / 64;
+    tile_off.assign(n_tiles + 1, 0);
+    for (size_t t = 0; t < n_tiles; t++) {
+        const uint64_t chunks = (uint64_t(n_bins[order[t * 64]]) + 7) / 8;   // sorted: first lane is the longest
+        tile_off[t + 1] = tile_off[t] + chunks * 64;
+    }
+}
+
+}  // namespace
+
+struct avr_batch {
+    int device = 0;
+    size_t max_slices = 0, max_bins = 0, total_bins = 0;
+    int kind = -1;
+    size_t n_states = 0;
+    bool ran = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {};
+    float ms[4] = {0, 0, 0, 0};
+
+    // host side
+    PinBuf<uint16_t> h_recs;
+    PinBuf<uint8_t> h_states, h_out, h_final;
+    PinBuf<uint32_t> h_out_len;
+    PinBuf<int32_t> h_status;
+    std::vector<uint64_t> rec_off;          // n+1, records, multiples of 8
+    std::vector<uint32_t> n_bins;
+    std::vector<uint64_t> dense_off;        // n+1, bytes in h_out
+
+    // device side
+    DevBuf<uint16_t> d_recs;
+    DevBuf<uint4> d_tiles;
+    DevBuf<uint64_t> d_rec_off, d_tile_off, d_out_off, d_dense_off;
+    DevBuf<uint32_t> d_n_bins, d_order, d_out_len;
+    DevBuf<int32_t> d_status;
+    DevBuf<uint8_t> d_states, d_final, d_out, d_dense;
+};
+
+extern "C" {
+
+const char *avr_last_error(void) { return g_err; }
+const char *avr_version(void) { return "avrecode-ms_amd 0.1 (gfx950)"; }
+
+int avr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const uint8_t *avr_cabac_lps_range_table(void) { return kTables.lps_range; }
+const uint8_t *avr_cabac_mlps_state_table(void) { return kTables.mlps_state; }
+
+// ------------------------------------------------------------------ batch API
+
+avr_batch *avr_batch_create(int device, size_t max_slices, size_t max_bins) {
+    if (max_slices == 0 || max_slices > 0x7fffffffu) { fail(AVR_ERR_INVALID, "max_slices out of range"); return nullptr; }
+    if (select_device(device) != AVR_OK) return nullptr;
+    avr_batch *b = new (std::nothrow) avr_batch;
+    if (!b) { fail(AVR_ERR_NOMEM, "out of host memory"); return nullptr; }
+    b->device = device;
+    b->max_slices = max_slices;
+    b->max_bins = max_bins;
+    bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 5; i++) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+    ok = ok && b->h_recs.reserve(max_bins + 8 * max_slices) == AVR_OK;
+    if (!ok) {
+        if (!g_err[0]) fail(AVR_ERR_HIP, "stream/event creation failed");
+        avr_batch_destroy(b);
+        return nullptr;
+    }
+    b->rec_off.reserve(max_slices + 1);
+    b->n_bins.reserve(max_slices);
+    b->rec_off.push_back(0);
+    return b;
+}
+
+void avr_batch_destroy(avr_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    b->h_recs.release(); b->h_states.release(); b->h_out.release(); b->h_final.release();
+    b->h_out_len.release(); b->h_status.release();
+    b->d_recs.release(); b->d_tiles.release(); b->d_rec_off.release(); b->d_tile_off.release();
+    b->d_out_off.release(); b->d_dense_off.release(); b->d_n_bins.release(); b->d_order.release();
+    b->d_out_len.release(); b->d_status.release(); b->d_states.release(); b->d_final.release();
+    b->d_out.release(); b->d_dense.release();
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int avr_batch_reset(avr_batch *b) {
+    if (!b) return fail(AVR_ERR_INVALID, "null batch");
+    b->kind = -1; b->n_states = 0; b->ran = false; b->total_bins = 0;
+    b->rec_off.assign(1, 0);
+    b->n_bins.clear();
+    b->dense_off.clear();
+    return AVR_OK;
+}
+
+static int add_slice(avr_batch *b, int kind, const uint16_t *recs, size_t n, const uint8_t *init_states, size_t n_states) {
+    if (!b) return fail(AVR_ERR_INVALID, "null batch");
+    if (!recs && n) return fail(AVR_ERR_INVALID, "null records");
+    if (b->ran) return fail(AVR_ERR_INVALID, "batch already ran; call avr_batch_reset first");
+    if (b->kind >= 0 && b->kind != kind) return fail(AVR_ERR_INVALID, "a batch holds slices of one kind only");
+    if (n > 0xfffffff0u) return fail(AVR_ERR_INVALID, "slice too long");
+    if (b->n_bins.size() >= b->max_slices) return fail(AVR_ERR_CAPACITY, "batch holds max_slices=%zu slices", b->max_slices);
+    const size_t idx = b->n_bins.size();
+    if (kind == AVR_KIND_CABAC) {
+        if (n_states > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "n_states %zu > %d", n_states, AVR_MAX_STATES);
+        if (!init_states && n_states) return fail(AVR_ERR_INVALID, "null init_states");
+        if (idx && n_states != b->n_states) return fail(AVR_ERR_INVALID, "all slices of a batch use the same n_states");
+        for (size_t i = 0; i < n_states; i++)
+            if (init_states[i] > 127) return fail(AVR_ERR_INVALID, "state byte %zu = %u is not 2*pStateIdx+valMPS", i, init_states[i]);
+        if (int rc = b->h_states.reserve(b->max_slices * std::max<size_t>(n_states, 1))) return rc;
+        b->n_states = n_states;
+        if (n_states) memcpy(b->h_states.p + idx * n_states, init_states, n_states);
+    }
+    const uint64_t off = b->rec_off.back();
+    const uint64_t padded = (uint64_t(n) + 7) & ~uint64_t(7);
+    if (b->total_bins + n > b->max_bins)
+        return fail(AVR_ERR_CAPACITY, "batch holds max_bins=%zu records", b->max_bins);
+    b->total_bins += n;
+    if (n) memcpy(b->h_recs.p + off, recs, n * sizeof(uint16_t));
+    if (padded > n) memset(b->h_recs.p + off + n, 0, (padded - n) * sizeof(uint16_t));
+    b->rec_off.push_back(off + padded);
+    b->n_bins.push_back(uint32_t(n));
+    b->kind = kind;
+    return int(idx);
+}
+
+int avr_batch_add_slice_cabac(avr_batch *b, const uint16_t *recs, size_t n, const uint8_t *init_states, size_t n_states) {
+    return add_slice(b, AVR_KIND_CABAC, recs, n, init_states, n_states);
+}
+
+int avr_batch_add_slice_range(avr_batch *b, const uint16_t *recs, size_t n) {
+    return add_slice(b, AVR_KIND_RANGE, recs, n, nullptr, 0);
+}
+
+int avr_batch_run(avr_batch *b) {
+    if (!b) return fail(AVR_ERR_INVALID, "null batch");
+    if (b->ran) return fail(AVR_ERR_INVALID, "batch already ran");
+    if (int rc = select_device(b->device)) return rc;
+    const size_t n = b->n_bins.size();
+    b->ran = true;
+    b->dense_off.assign(n + 1, 0);
+    if (n == 0) return AVR_OK;
+    const uint32_t n32 = uint32_t(n);
+    const size_t ns = b->n_states;
+    const bool cabac = b->kind == AVR_KIND_CABAC;
+
+    std::vector<uint32_t> order;
+    std::vector<uint64_t> tile_off, out_off(n + 1, 0);
+    plan_tiles(b->n_bins, order, tile_off);
+    // worst case is 8 bits per bin for either coder ("output sizing") + stop bytes
+    for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + ((uint64_t(b->n_bins[i]) + 16 + 7) & ~uint64_t(7));
+    const uint64_t total_recs = b->rec_off.back(), total_chunks = tile_off.back(), total_out = out_off.back();
+    const size_t n_tiles = tile_off.size() - 1;
+
+    int rc;
+    if ((rc = b->d_recs.reserve(total_recs)) || (rc = b->d_tiles.reserve(total_chunks)) ||
+        (rc = b->d_rec_off.reserve(n + 1)) || (rc = b->d_tile_off.reserve(n_tiles + 1)) ||
+        (rc = b->d_out_off.reserve(n + 1)) || (rc = b->d_dense_off.reserve(n + 1)) ||
+        (rc = b->d_n_bins.reserve(n)) || (rc = b->d_order.reserve(n)) || (rc = b->d_out_len.reserve(n)) ||
+        (rc = b->d_status.reserve(n)) || (rc = b->d_out.reserve(total_out)) ||
+        (rc = b->h_out_len.reserve(n)) || (rc = b->h_status.reserve(n)))
+        return rc;
+    if (cabac && ((rc = b->d_states.reserve(n * std::max<size_t>(ns, 1))) || (rc = b->d_final.reserve(n * std::max<size_t>(ns, 1))) ||
+                  (rc = b->h_final.reserve(n * std::max<size_t>(ns, 1)))))
+        return rc;
+
+    hipStream_t s = b->stream;
+    AVR_HIP(hipEventRecord(b->ev[0], s));
+    AVR_HIP(hipMemcpyAsync(b->d_recs.p, b->h_recs.p, total_recs * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_rec_off.p, b->rec_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_tile_off.p, tile_off.data(), (n_tiles + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_out_off.p, out_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_n_bins.p, b->n_bins.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_order.p, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    if (cabac && ns) AVR_HIP(hipMemcpyAsync(b->d_states.p, b->h_states.p, n * ns, hipMemcpyHostToDevice, s));
+    // the vectors above are pageable: the copies have been staged by the runtime when the calls return
+    AVR_HIP(hipEventRecord(b->ev[1], s));
+    AVR_HIP(avr::launch_pack_tiles(s, b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_tile_off.p, b->d_tiles.p));
+    AVR_HIP(hipEventRecord(b->ev[2], s));
+    if (cabac)
+        AVR_HIP(avr::launch_cabac_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_states.p,
+                                         uint32_t(ns), b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p, b->d_final.p));
+    else
+        AVR_HIP(avr::launch_range_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_out.p,
+                                         b->d_out_off.p, b->d_out_len.p, b->d_status.p));
+    AVR_HIP(hipEventRecord(b->ev[3], s));
+    AVR_HIP(hipMemcpyAsync(b->h_out_len.p, b->d_out_len.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    AVR_HIP(hipMemcpyAsync(b->h_status.p, b->d_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (cabac && ns) AVR_HIP(hipMemcpyAsync(b->h_final.p, b->d_final.p, n * ns, hipMemcpyDeviceToHost, s));
+    AVR_HIP(hipStreamSynchronize(s));
+
+    // gather the coded bytes densely on the device, then one D2H copy
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t cap = out_off[i + 1] - out_off[i];
+        b->dense_off[i + 1] = b->dense_off[i] + std::min<uint64_t>(b->h_out_len.p[i], cap);
+    }
+    const uint64_t dense_total = b->dense_off.back();
+    if ((rc = b->d_dense.reserve(dense_total + 1)) || (rc = b->h_out.reserve(dense_total + 1))) return rc;
+    AVR_HIP(hipMemcpyAsync(b->d_dense_off.p, b->dense_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    AVR_HIP(avr::launch_compact(s, b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_dense_off.p, n32, b->d_dense.p));
+    if (dense_total) AVR_HIP(hipMemcpyAsync(b->h_out.p, b->d_dense.p, dense_total, hipMemcpyDeviceToHost, s));
+    AVR_HIP(hipEventRecord(b->ev[4], s));
+    AVR_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&b->ms[i], b->ev[i], b->ev[i + 1]);
+    return AVR_OK;
+}
+
+int avr_batch_get(avr_batch *b, size_t slice, const uint8_t **bytes, size_t *len, int *status) {
+    if (!b || !b->ran) return fail(AVR_ERR_INVALID, "batch has not run");
+    if (slice >= b->n_bins.size()) return fail(AVR_ERR_INVALID, "slice %zu out of range", slice);
+    if (bytes) *bytes = b->h_out.p + b->dense_off[slice];
+    if (len) *len = size_t(b->dense_off[slice + 1] - b->dense_off[slice]);
+    if (status) *status = b->h_status.p[slice];
+    return AVR_OK;
+}
+
+int avr_batch_get_states(avr_batch *b, size_t slice, const uint8_t **states, size_t *n_states) {
+    if (!b || !b->ran) return fail(AVR_ERR_INVALID, "batch has not run");
+    if (b->kind != AVR_KIND_CABAC) return fail(AVR_ERR_INVALID, "not a CABAC batch");
+    if (slice >= b->n_bins.size()) return fail(AVR_ERR_INVALID, "slice %zu out of range", slice);
+    if (states) *states = b->h_final.p + slice * b->n_states;
+    if (n_states) *n_states = b->n_states;
+    return AVR_OK;
+}
+
+int avr_batch_timings(avr_batch *b, float ms[4]) {
+    if (!b || !b->ran || !ms) return fail(AVR_ERR_INVALID, "batch has not run");
+    memcpy(ms, b->ms, sizeof b->ms);
+    return AVR_OK;
+}
+
+// ------------------------------------------------------------------ device-resident API
+
+static int check_common(const void *a, const void *b, const void *c, size_t n_slices) {
+    if (n_slices > 0x7fffffffu) return fail(AVR_ERR_INVALID, "n_slices out of range");
+    if (n_slices && (!a || !b || !c)) return fail(AVR_ERR_INVALID, "null device pointer");
+    return AVR_OK;
+}
+
+int avr_pack_tiles_device(int device, void *stream, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                          const uint32_t *order, size_t n_slices, const uint64_t *tile_off, void *tiles) {
+    if (int rc = check_common(rec_off, n_bins, tile_off, n_slices)) return rc;
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_pack_tiles(static_cast<hipStream_t>(stream), recs, rec_off, n_bins, order, uint32_t(n_slices), tile_off, tiles));
+    return AVR_OK;
+}
+
+int avr_cabac_encode_tiles_device(int device, void *stream, const void *tiles, const uint64_t *tile_off, const uint32_t *n_bins,
+                                  const uint32_t *order, size_t n_slices, const uint8_t *init_states, size_t n_states,
+                                  uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status, uint8_t *final_states) {
+    if (int rc = check_common(tile_off, n_bins, out_off, n_slices)) return rc;
+    if (n_states > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "n_states %zu > %d", n_states, AVR_MAX_STATES);
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_cabac_encode(true, static_cast<hipStream_t>(stream), tiles, tile_off, n_bins, order, uint32_t(n_slices),
+                                     init_states, uint32_t(n_states), out, out_off, out_len, status, final_states));
+    return AVR_OK;
+}
+
+int avr_range_encode_tiles_device(int device, void *stream, const void *tiles, const uint64_t *tile_off, const uint32_t *n_bins,
+                                  const uint32_t *order, size_t n_slices, uint8_t *out, const uint64_t *out_off,
+                                  uint32_t *out_len, int32_t *status) {
+    if (int rc = check_common(tile_off, n_bins, out_off, n_slices)) return rc;
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_range_encode(true, static_cast<hipStream_t>(stream), tiles, tile_off, n_bins, order, uint32_t(n_slices),
+                                     out, out_off, out_len, status));
+    return AVR_OK;
+}
+
+int avr_cabac_encode_slices_device(int device, void *stream, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                                   const uint32_t *order, size_t n_slices, const uint8_t *init_states, size_t n_states,
+                                   uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status, uint8_t *final_states) {
+    if (int rc = check_common(rec_off, n_bins, out_off, n_slices)) return rc;
+    if (n_states > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "n_states %zu > %d", n_states, AVR_MAX_STATES);
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_cabac_encode(false, static_cast<hipStream_t>(stream), recs, rec_off, n_bins, order, uint32_t(n_slices),
+                                     init_states, uint32_t(n_states), out, out_off, out_len, status, final_states));
+    return AVR_OK;
+}
+
+int avr_range_encode_slices_device(int device, void *stream, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                                   const uint32_t *order, size_t n_slices, uint8_t *out, const uint64_t *out_off,
+                                   uint32_t *out_len, int32_t *status) {
+    if (int rc = check_common(rec_off, n_bins, out_off, n_slices)) return rc;
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_range_encode(false, static_cast<hipStream_t>(stream), recs, rec_off, n_bins, order, uint32_t(n_slices),
+                                     out, out_off, out_len, status));
+    return AVR_OK;
+}
+
+// ------------------------------------------------------------------ synthetic streams
+
+int avr_synth_config_init(avr_synth_config *cfg, int workload, uint32_t scale_permille, uint64_t first_slice) {
+    if (!cfg) return fail(AVR_ERR_INVALID, "null config");
+    if (workload < 2 || workload > 5) return fail(AVR_ERR_INVALID, "workload %d: expected 2..5 (BASELINE.json configs)", workload);
+    if (scale_permille == 0) return fail(AVR_ERR_INVALID, "scale_permille must be > 0");
+    cfg->workload = workload;
+    cfg->scale_permille = scale_permille;
+    cfg->seed = 0x5EED0000ull + uint64_t(workload);     // SURVEY.md 8(d) seeds
+    cfg->first_slice = first_slice;
+    cfg->n_states = avr::synth_shape(workload, scale_permille, cfg->seed, 0).n_states;
+    return AVR_OK;
+}
+
+namespace {
+struct HostRecordSink {
+    uint16_t *dst;
+    uint32_t n = 0;
+    void put_record(uint16_t r) { dst[n++] = r; }
+};
+}  // namespace
+
+int avr_synth_count_host(const avr_synth_config *cfg, int kind, size_t n_slices, uint32_t *n_bins) {
+    if (!cfg || (!n_bins && n_slices)) return fail(AVR_ERR_INVALID, "null argument");
+    (void)kind;
+    for (size_t i = 0; i < n_slices; i++) {
+        avr::CountSink cs;
+        avr::CabacSink<avr::CountSink> sink(cs);
+        avr::synth_slice(cfg->workload, cfg->scale_permille, cfg->seed, cfg->first_slice + i, sink);
+        n_bins[i] = cs.n;
+    }
+    return AVR_OK;
+}
+
+int avr_synth_generate_host(const avr_synth_config *cfg, int kind, size_t n_slices, const uint64_t *rec_off, uint16_t *recs,
+                            uint8_t *init_states) {
+    if (!cfg || ((!rec_off || !recs) && n_slices)) return fail(AVR_ERR_INVALID, "null argument");
+    for (size_t i = 0; i < n_slices; i++) {
+        HostRecordSink rs{recs + rec_off[i]};
+        if (kind == AVR_KIND_CABAC) {
+            avr::CabacSink<HostRecordSink> sink(rs);
+            avr::synth_slice(cfg->workload, cfg->scale_permille, cfg->seed, cfg->first_slice + i, sink);
+            if (init_states)
+                for (uint32_t c = 0; c < cfg->n_states; c++)
+                    init_states[i * cfg->n_states + c] = avr::synth_init_state(c, cfg->seed, cfg->first_slice + i);
+        } else {
+            avr::ModelSink<HostRecordSink> sink(rs);
+            avr::synth_slice(cfg->workload, cfg->scale_permille, cfg->seed, cfg->first_slice + i, sink);
+        }
+    }
+    return AVR_OK;
+}
+
+int avr_synth_count_device(int device, void *stream, const avr_synth_config *cfg, int kind, size_t n_slices, uint32_t *n_bins) {
+    if (!cfg || (!n_bins && n_slices) || n_slices > 0x7fffffffu) return fail(AVR_ERR_INVALID, "bad argument");
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_synth_count(static_cast<hipStream_t>(stream), cfg->workload, cfg->scale_permille, cfg->seed, cfg->first_slice,
+                                    kind, uint32_t(n_slices), n_bins));
+    return AVR_OK;
+}
+
+int avr_synth_generate_tiles_device(int device, void *stream, const avr_synth_config *cfg, int kind, size_t n_slices,
+                                    const uint32_t *order, const uint64_t *tile_off, void *tiles, uint8_t *init_states) {
+    if (!cfg || ((!tile_off || !tiles) && n_slices) || n_slices > 0x7fffffffu) return fail(AVR_ERR_INVALID, "bad argument");
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_synth_tiles(static_cast<hipStream_t>(stream), cfg->workload, cfg->scale_permille, cfg->seed, cfg->first_slice,
+                                    kind, uint32_t(n_slices), order, tile_off, tiles, init_states, cfg->n_states));
+    return AVR_OK;
+}
+
+// ------------------------------------------------------------------ host epilogue helpers
+
+size_t avr_drop_stop_byte(const uint8_t *buf, size_t len) {
+    // decompressor::cabac_decoder::finish, recode.cpp:1508-1512
+    return (len > 0 && buf[len - 1] == 0x80) ? len - 1 : len;
+}
+
+size_t avr_tail_patch(uint8_t *buf, size_t len, int length_parity, uint8_t last_byte) {
+    // decompressor::run, recode.cpp:1354-1360
+    if (length_parity == -1) return len;
+    if (length_parity != int(len & 1)) { buf[len] = last_byte; return len + 1; }
+    if (len > 0) buf[len - 1] = last_byte;
+    return len;
+}
+
+}  // extern "C"

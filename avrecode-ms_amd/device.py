@@ -1,0 +1,173 @@
+"""Device-resident helpers: torch owns the HBM buffers and the stream, the C ABI does the work.
+
+torch is plumbing only (allocation, streams, torch.distributed in bench.py); every
+function here ends in a call through ``include/avrecode_ms_amd.h``.
+"""
+from __future__ import annotations
+
+import ctypes
+
+from . import KIND_CABAC, KIND_RANGE, AvrError, SynthConfig, _check, lib
+
+
+def synth_config(workload: int, scale_permille: int = 1000, first_slice: int = 0) -> SynthConfig:
+    cfg = SynthConfig()
+    _check(lib().avr_synth_config_init(ctypes.byref(cfg), workload, scale_permille, first_slice))
+    return cfg
+
+
+def _stream_ptr(torch):
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def plan_tiles(n_bins):
+    """Processing order and tile offsets for per-slice bin counts (int32 tensor, any device).
+
+    Slices are processed longest first, 64 per tile (one wave); a tile is as long as its
+    longest slice.  Returns (order int32[n], tile_off int64[n_tiles+1] in 16-byte chunks).
+    Same plan as plan_tiles() in csrc/avr_api.cpp.
+    """
+    import torch
+    n = n_bins.numel()
+    order = torch.argsort(n_bins.to(torch.int64), descending=True, stable=True)
+    chunks = (n_bins.to(torch.int64)[order] + 7) // 8
+    tile_max = chunks[::64]
+    tile_off = torch.zeros(tile_max.numel() + 1, dtype=torch.int64, device=n_bins.device)
+    tile_off[1:] = torch.cumsum(tile_max * 64, 0)
+    return order.to(torch.int32), tile_off
+
+
+def encode_tiles(kind, tiles, tile_off, n_bins, order, out, out_off, out_len, status,
+                 init_states=None, n_states=0, final_states=None, device_index=0):
+    """Enqueue K1 (kind 0) or K2 (kind 1) on torch's current stream."""
+    import torch
+    L = lib()
+    n = n_bins.numel()
+    sp = _stream_ptr(torch)
+    if kind == KIND_CABAC:
+        _check(L.avr_cabac_encode_tiles_device(
+            device_index, sp, tiles.data_ptr(), tile_off.data_ptr(), n_bins.data_ptr(), order.data_ptr(), n,
+            init_states.data_ptr() if init_states is not None else None, n_states,
+            out.data_ptr(), out_off.data_ptr(), out_len.data_ptr(), status.data_ptr(),
+            final_states.data_ptr() if final_states is not None else None))
+    else:
+        _check(L.avr_range_encode_tiles_device(
+            device_index, sp, tiles.data_ptr(), tile_off.data_ptr(), n_bins.data_ptr(), order.data_ptr(), n,
+            out.data_ptr(), out_off.data_ptr(), out_len.data_ptr(), status.data_ptr()))
+
+
+class DeviceWorkload:
+    """A batch of slices resident in HBM in the wave-interleaved tile layout."""
+
+    def __init__(self, kind, device_index, n_bins, order, tile_off, tiles, init_states, n_states):
+        import torch
+        self.kind, self.device_index = kind, device_index
+        self.n_bins, self.order, self.tile_off, self.tiles = n_bins, order, tile_off, tiles
+        self.init_states, self.n_states = init_states, n_states
+        self.n_slices = n_bins.numel()
+        dev = n_bins.device
+        cap = (n_bins.to(torch.int64) + 16 + 7) // 8 * 8          # worst case 8 bits per bin + stop bytes
+        self.out_off = torch.zeros(self.n_slices + 1, dtype=torch.int64, device=dev)
+        self.out_off[1:] = torch.cumsum(cap, 0)
+        self.out = torch.empty(int(self.out_off[-1].item()), dtype=torch.uint8, device=dev)
+        self.out_len = torch.zeros(self.n_slices, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(self.n_slices, dtype=torch.int32, device=dev)
+        self.final_states = (torch.empty(self.n_slices * max(n_states, 1), dtype=torch.uint8, device=dev)
+                             if kind == KIND_CABAC else None)
+        self.total_bins = int(n_bins.to(torch.int64).sum().item())
+
+    @classmethod
+    def synth(cls, workload, n_slices, kind=KIND_CABAC, device_index=0, scale_permille=1000, first_slice=0):
+        """Generate BASELINE.json config `workload` on the device (avr_synth_*_device)."""
+        import torch
+        L = lib()
+        dev = torch.device("cuda", device_index)
+        cfg = synth_config(workload, scale_permille, first_slice)
+        with torch.cuda.device(dev):
+            sp = _stream_ptr(torch)
+            n_bins = torch.zeros(n_slices, dtype=torch.int32, device=dev)
+            _check(L.avr_synth_count_device(device_index, sp, ctypes.byref(cfg), kind, n_slices, n_bins.data_ptr()))
+            order, tile_off = plan_tiles(n_bins)
+            tiles = torch.empty(int(tile_off[-1].item()) * 16, dtype=torch.uint8, device=dev)
+            init_states = (torch.empty(n_slices * cfg.n_states, dtype=torch.uint8, device=dev)
+                           if kind == KIND_CABAC else None)
+            _check(L.avr_synth_generate_tiles_device(
+                device_index, sp, ctypes.byref(cfg), kind, n_slices, order.data_ptr(), tile_off.data_ptr(),
+                tiles.data_ptr(), init_states.data_ptr() if init_states is not None else None))
+            torch.cuda.synchronize(dev)
+        w = cls(kind, device_index, n_bins, order, tile_off, tiles, init_states, cfg.n_states if kind == KIND_CABAC else 0)
+        w.cfg = cfg
+        return w
+
+    @classmethod
+    def from_host(cls, kind, recs_list, init_states_list=None, device_index=0):
+        """Upload per-slice uint16 record arrays and pack them into tiles on the device."""
+        import numpy as np
+        import torch
+        L = lib()
+        dev = torch.device("cuda", device_index)
+        n = len(recs_list)
+        nb = np.array([len(r) for r in recs_list], dtype=np.int32)
+        padded = (nb.astype(np.int64) + 7) // 8 * 8
+        rec_off = np.zeros(n + 1, dtype=np.int64)
+        rec_off[1:] = np.cumsum(padded)
+        flat = np.zeros(int(rec_off[-1]) + 8, dtype=np.uint16)
+        for i, r in enumerate(recs_list):
+            flat[rec_off[i]:rec_off[i] + len(r)] = r
+        n_states = len(init_states_list[0]) if (kind == KIND_CABAC and init_states_list) else 0
+        with torch.cuda.device(dev):
+            d_flat = torch.from_numpy(flat.view(np.int16)).to(dev)
+            d_off = torch.from_numpy(rec_off).to(dev)
+            n_bins = torch.from_numpy(nb).to(dev)
+            order, tile_off = plan_tiles(n_bins)
+            tiles = torch.empty(max(int(tile_off[-1].item()), 1) * 16, dtype=torch.uint8, device=dev)
+            _check(L.avr_pack_tiles_device(device_index, _stream_ptr(torch), d_flat.data_ptr(), d_off.data_ptr(),
+                                           n_bins.data_ptr(), order.data_ptr(), n, tile_off.data_ptr(), tiles.data_ptr()))
+            init = None
+            if kind == KIND_CABAC:
+                init = torch.from_numpy(np.concatenate([np.asarray(s, dtype=np.uint8) for s in init_states_list])
+                                        if n_states else np.zeros(1, np.uint8)).to(dev)
+            torch.cuda.synchronize(dev)
+        w = cls(kind, device_index, n_bins, order, tile_off, tiles, init, n_states)
+        w.rec_flat, w.rec_off = d_flat, d_off
+        return w
+
+    def encode(self):
+        """One pass of the hot path over the batch (enqueued on torch's current stream)."""
+        encode_tiles(self.kind, self.tiles, self.tile_off, self.n_bins, self.order, self.out, self.out_off,
+                     self.out_len, self.status, self.init_states, self.n_states, self.final_states, self.device_index)
+
+    def encode_slice_major(self):
+        """Same result from the slice-major layout (only for workloads built with from_host)."""
+        import torch
+        L = lib()
+        sp = _stream_ptr(torch)
+        if self.kind == KIND_CABAC:
+            _check(L.avr_cabac_encode_slices_device(
+                self.device_index, sp, self.rec_flat.data_ptr(), self.rec_off.data_ptr(), self.n_bins.data_ptr(),
+                self.order.data_ptr(), self.n_slices, self.init_states.data_ptr(), self.n_states, self.out.data_ptr(),
+                self.out_off.data_ptr(), self.out_len.data_ptr(), self.status.data_ptr(), self.final_states.data_ptr()))
+        else:
+            _check(L.avr_range_encode_slices_device(
+                self.device_index, sp, self.rec_flat.data_ptr(), self.rec_off.data_ptr(), self.n_bins.data_ptr(),
+                self.order.data_ptr(), self.n_slices, self.out.data_ptr(), self.out_off.data_ptr(),
+                self.out_len.data_ptr(), self.status.data_ptr()))
+
+    # ---- accounting (DESIGN.md "algorithmic bytes")
+    def output_bytes(self) -> int:
+        import torch
+        return int(self.out_len.to(torch.int64).sum().item())
+
+    def algorithmic_bytes(self) -> int:
+        """2*n_bins + n_states*n_slices (K1) + out_bytes + 16*n_slices."""
+        states = self.n_states * self.n_slices if self.kind == KIND_CABAC else 0
+        return 2 * self.total_bins + states + self.output_bytes() + 16 * self.n_slices
+
+    def results(self):
+        """(list of bytes per slice, status list) copied to the host."""
+        import torch
+        torch.cuda.synchronize(self.out.device)
+        out, off = self.out.cpu().numpy(), self.out_off.cpu().numpy()
+        lens, st = self.out_len.cpu().numpy(), self.status.cpu().numpy()
+        return [out[off[i]:off[i] + min(int(lens[i]), int(off[i + 1] - off[i]))].tobytes()
+                for i in range(self.n_slices)], st.tolist()

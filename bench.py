@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- H.264 bytes/s of the arithmetic re-encode hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 2|3|4|5] [--kind cabac|range]
+
+A step is one pass of the hot path over one batch of synthetic slices that is already
+resident in HBM (wave-interleaved tiles, generated on the device from seeded streams,
+SURVEY.md 8(d)).  Default workload: BASELINE.json configs[1] -- 512 slices of a 1080p30
+clip, 1 slice per frame -- on every rank (weak scaling: rank r owns slices
+[r*512, (r+1)*512) of the seeded stream space; no data-path collective).
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline      dominant kernel (the encode kernel): algorithmic bytes per launch / average
+                launch duration (HIP events on the launching stream) against HBM peak
+  cpu_baseline  the same coding done on the host CPU cores over a bounded sample of the same
+                workload: oracle/_ref (the reference's own arithmetic_code.h) when it has been
+                built, else the oracle restatement; GPU output is byte-compared with it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
+DEFAULT_SLICES = {2: 512, 3: 4096, 4: 16384, 5: 1 << 20}
+WORKLOAD_NAME = {
+    2: "config2: 1080p30 CABAC clip, 1 slice/frame, 512 frames (synthetic, 8160 MB/slice)",
+    3: "config3: 16 files x 256 slices, log-normal slice sizes (synthetic)",
+    4: "config4: 4K60, 8 slices/frame, 16384 slices (synthetic, 4080 MB/slice)",
+    5: "config5: residual-only streams, 1M slices x 64 4x4 blocks (synthetic)",
+}
+
+
+def cpu_baseline(avr, workload, kind, n_slices, first_slice, gpu_bytes_of, budget_s=20.0):
+    """Time the CPU checker on a bounded sample and byte-compare the GPU output with it."""
+    import ctypes
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle = oracle_lib.load_oracle()
+    ref = oracle_lib.load_ref() if kind == avr.KIND_CABAC else None
+    cores = max(1, len(os.sched_getaffinity(0)))
+    L = avr.lib()
+    cfg = avr.synth_config(workload, 1000, first_slice)
+    nb_all = np.zeros(n_slices, dtype=np.uint32)
+    L.avr_synth_count_host(ctypes.byref(cfg), kind, n_slices, nb_all.ctypes.data)
+    # bounded sample: as many leading slices as ~budget_s of CPU work allows at ~40 Mbin/s/core
+    max_bins = int(budget_s * 40e6 * cores)
+    cum = np.cumsum(nb_all.astype(np.int64))
+    m = int(min(n_slices, max(1, np.searchsorted(cum, max_bins))))
+    nb = nb_all[:m]
+    off = np.zeros(m + 1, dtype=np.uint64)
+    off[1:] = np.cumsum((nb.astype(np.uint64) + 7) // 8 * 8)
+    recs = np.zeros(int(off[-1]), dtype=np.uint16)
+    states = np.zeros(m * cfg.n_states, dtype=np.uint8)
+    L.avr_synth_generate_host(ctypes.byref(cfg), kind, m, off.ctypes.data, recs.ctypes.data, states.ctypes.data)
+    out_off = np.zeros(m + 1, dtype=np.uint64)
+    out_off[1:] = np.cumsum(nb.astype(np.uint64) + 16)
+    out = np.zeros(int(out_off[-1]), dtype=np.uint8)
+    out_len = np.zeros(m, dtype=np.uint32)
+    status = np.zeros(m, dtype=np.int32)
+    P = oracle_lib.ptr
+    # slice-exact offsets for the checker (records are padded to 8 per slice in `recs`)
+    roff = off.copy()
+
+    def run_port(threads):
+        # the oracle batch helper wants [off[i], off[i+1]) == the slice: call per contiguous run
+        rc = oracle.L.avr_oracle_encode_batch(
+            ctypes.c_int(kind), P(recs_c), P(roff_c), ctypes.c_size_t(m), P(states if kind == avr.KIND_CABAC else None),
+            ctypes.c_size_t(cfg.n_states if kind == avr.KIND_CABAC else 0), P(out), P(out_off), P(out_len), P(status),
+            ctypes.c_int(threads))
+        assert rc == 0
+
+    # compact copy without padding so that off[i+1]-off[i] is the slice length
+    parts = [recs[int(off[i]):int(off[i]) + int(nb[i])] for i in range(m)]
+    recs_c = np.concatenate(parts) if parts else np.zeros(0, np.uint16)
+    roff_c = np.zeros(m + 1, dtype=np.uint64)
+    roff_c[1:] = np.cumsum(nb.astype(np.uint64))
+
+    def run_ref(threads):
+        from concurrent.futures import ThreadPoolExecutor
+        bounds = np.linspace(0, m, threads * 4 + 1).astype(int)
+
+        def work(k):
+            lo, hi = int(bounds[k]), int(bounds[k + 1])
+            if hi > lo:
+                ref.L.ref_cabac_encode_batch(
+                    P(recs_c), ctypes.c_void_p(roff_c.ctypes.data + 8 * lo), ctypes.c_size_t(hi - lo),
+                    ctypes.c_void_p(states.ctypes.data + lo * cfg.n_states), ctypes.c_size_t(cfg.n_states),
+                    P(out), ctypes.c_void_p(out_off.ctypes.data + 8 * lo), ctypes.c_void_p(out_len.ctypes.data + 4 * lo))
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(work, range(threads * 4)))
+
+    kind_name, runner = ("reference", run_ref) if ref is not None else ("port", run_port)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        runner(cores)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        if dt > budget_s / 2:
+            break
+    cpu_bytes = [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(m)]
+    total = sum(len(b) for b in cpu_bytes)
+    # single-thread figure (the reference itself is single-threaded, recode.cpp:129) on a smaller cut
+    m1 = max(1, min(m, int(np.searchsorted(np.cumsum(nb.astype(np.int64)), 60e6)) + 1))
+    save = (m,)
+    t0 = time.perf_counter()
+    if ref is not None:
+        ref.L.ref_cabac_encode_batch(P(recs_c), P(roff_c), ctypes.c_size_t(m1), P(states), ctypes.c_size_t(cfg.n_states),
+                                     P(out), P(out_off), P(out_len))
+    else:
+        oracle.L.avr_oracle_encode_batch(ctypes.c_int(kind), P(recs_c), P(roff_c), ctypes.c_size_t(m1),
+                                         P(states if kind == avr.KIND_CABAC else None),
+                                         ctypes.c_size_t(cfg.n_states if kind == avr.KIND_CABAC else 0), P(out), P(out_off),
+                                         P(out_len), P(status), ctypes.c_int(1))
+    dt1 = time.perf_counter() - t0
+    bytes1 = sum(len(b) for b in cpu_bytes[:m1])
+    gpu = gpu_bytes_of(m)
+    parity = "bit-exact" if gpu == cpu_bytes else "MISMATCH"
+    return {
+        "value": total / best, "unit": "bytes/s", "cores": cores, "kind": kind_name,
+        "sample": f"first {m} of {n_slices} slices of the same workload ({int(nb.astype(np.int64).sum())} bins, "
+                  f"{total} H.264 bytes), best of <=3, one slice per task",
+        "single_thread_value": bytes1 / dt1,
+        "parity_vs_gpu": parity, "parity_slices": m,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--kind", default="cabac", choices=["cabac", "range"])
+    ap.add_argument("--slices", type=int, default=0, help="slices per rank (default: the configuration's own count)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import avrecode_ms_amd as avr
+    from avrecode_ms_amd.sharding import reduce_timing, shard_first_slice
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available() or avr.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    kind = avr.KIND_CABAC if args.kind == "cabac" else avr.KIND_RANGE
+
+    n_slices = args.slices or DEFAULT_SLICES[args.workload]
+    first = shard_first_slice(rank, n_slices)
+    w = avr.DeviceWorkload.synth(args.workload, n_slices, kind, local_rank, 1000, first)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        w.encode()
+    sync_all()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record()               # w.encode() launches on torch's current stream
+        w.encode()
+        ends[i].record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / max(args.steps, 1)
+
+    out_bytes = w.output_bytes()
+    status_bad = int((w.status != 0).sum().item())
+    t_max, total_bytes = reduce_timing(dist if world > 1 else None, elapsed, out_bytes * args.steps, dev)
+
+    if rank == 0:
+        algo = w.algorithmic_bytes()
+        achieved = algo / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.kind}_w{args.workload}_s{n_slices}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "H.264 bytes/s recompressed (CABAC re-encode of recorded bin streams, bit-exact vs CPU)",
+            "value": total_bytes / t_max, "unit": "bytes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32" if kind == avr.KIND_CABAC else "u64", "data": "synthetic",
+            "config": {"workload": WORKLOAD_NAME[args.workload], "kernel": "K1 cabac_encode" if kind == avr.KIND_CABAC else "K2 range_encode",
+                       "slices_per_gpu": n_slices, "bins_per_gpu": w.total_bins, "h264_bytes_per_gpu": out_bytes,
+                       "n_states": w.n_states, "layout": "wave-interleaved tiles", "parallelism": f"slice-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "k_cabac_encode<tiled>" if kind == avr.KIND_CABAC else "k_range_encode<tiled>",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
+                         "bins_per_s": w.total_bins / (kernel_ms * 1e-3)},
+            "slice_status_errors": status_bad,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            def gpu_bytes_of(m):
+                return w.results()[0][:m]
+            line["cpu_baseline"] = cpu_baseline(avr, args.workload, kind, n_slices, first, gpu_bytes_of)
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,200 @@
+/*
+ * avrecode_ms_amd.h -- C ABI of the MI355X-native arithmetic re-encode path.
+ *
+ * Shared library: avrecode-ms_amd/libavrecode_hip.so (built by __graft_entry__.build()).
+ * Plain C: pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * What this replaces in the reference (pbluc/avrecode-ms, paths relative to
+ * /root/reference):
+ *
+ *   The reference codes every CABAC bin inline, inside the libavcodec hook
+ *   callbacks (recode.cpp:149-171 -> Driver::cabac_decoder::get / get_bypass /
+ *   get_terminate):
+ *     compress    recode.cpp:1182-1199 -> h264_symbol::execute :1075-1103
+ *                 -> recoded_code::encoder::put (arithmetic_code.h:106-126)
+ *     decompress  recode.cpp:1442-1481
+ *                 -> cabac::encoder::put / put_bypass / put_terminate (cabac_code.h:33-67)
+ *   Nothing consumes the coded bytes before the end of the run
+ *   (recode.cpp:1131 SerializeAsString, :1352-1363 final loop), so the build's
+ *   hook adapter RECORDS one 16-bit record per bin and hands whole batches of
+ *   independent slices to the device here.  The entry points are what a cgo /
+ *   JNI / ctypes binding -- or the reference's own C++ -- would bind; the
+ *   reference-side patch is shown in INTEGRATION.md.
+ *
+ * Record formats
+ *   CABAC record (K1, decompress direction), uint16_t:
+ *       bit 0      bin value
+ *       bits 1..11 selector: 0..1023  context index = offset of the `uint8_t *state`
+ *                                     handed to get() from the slice's first state
+ *                                     (recode.cpp:156, context identity is the address, :325)
+ *                            1024     bypass     (get_bypass,    recode.cpp:1458-1467)
+ *                            1025     terminate  (get_terminate, recode.cpp:1469-1481)
+ *   range record (K2, compress direction), uint16_t:
+ *       bit 0      bin value
+ *       bits 1..7  pos, bits 8..14 neg : the {pos,neg} estimator of the bin's model key at
+ *                  the moment it is coded (recode.cpp:823-827, 1064); p(1) = (range/(pos+neg))*pos
+ *
+ * Threading: one avr_batch per host thread; calls on different batches are
+ * independent.  Errors: functions return AVR_OK (0) or a negative AVR_ERR_*;
+ * avr_last_error() gives the message for the calling thread.  The reference
+ * throws C++ exceptions through its C callbacks instead (recode.cpp:43,71,99,169,
+ * arithmetic_code.h:117); the host wrapper re-throws from these codes.
+ */
+#ifndef AVRECODE_MS_AMD_H
+#define AVRECODE_MS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVR_OK              0
+#define AVR_ERR_INVALID    -1   /* bad argument / call order */
+#define AVR_ERR_NO_DEVICE  -2   /* no HIP device: there is NO CPU fallback */
+#define AVR_ERR_HIP        -3   /* a HIP runtime call failed */
+#define AVR_ERR_NOMEM      -4
+#define AVR_ERR_CAPACITY   -5   /* more slices / bins than the batch was created for */
+
+/* per-slice status written by the kernels */
+#define AVR_SLICE_OK          0
+#define AVR_SLICE_ZERO_PROB   1  /* arithmetic_code.h:116-118 "emitted a zero-probability symbol" */
+#define AVR_SLICE_OVERFLOW    2  /* output region too small (never with the batch API's sizing) */
+#define AVR_SLICE_BAD_RECORD  3  /* selector out of range, or a bin after put_terminate(1) */
+
+#define AVR_SEL_BYPASS     1024
+#define AVR_SEL_TERMINATE  1025
+#define AVR_MAX_STATES     1024  /* size of libavcodec's per-slice cabac_state[] */
+
+#define AVR_KIND_CABAC 0         /* K1: cabac::encoder           (cabac_code.h:26-82)   */
+#define AVR_KIND_RANGE 1         /* K2: recoded_code::encoder    (recode.cpp:322-323)   */
+
+const char *avr_last_error(void);
+const char *avr_version(void);
+int  avr_device_count(void);                 /* 0 when no GPU is visible */
+
+/* The CABAC tables in the layout cabac_code.h:11-12 indexes (512 and 256 bytes). */
+const uint8_t *avr_cabac_lps_range_table(void);
+const uint8_t *avr_cabac_mlps_state_table(void);
+
+/* ------------------------------------------------------------------ batch API (host memory)
+ * Replaces the per-bin encoder calls of Driver::cabac_decoder (see above).  Usage:
+ *   b = avr_batch_create(dev, max_slices, max_bins);
+ *   per slice:  avr_batch_add_slice_cabac(...) | avr_batch_add_slice_range(...)
+ *   avr_batch_run(b);                      // H2D, pack, encode kernel, D2H
+ *   per slice:  avr_batch_get(b, i, &bytes, &len, &status);
+ * A batch holds slices of one kind only.  Returned pointers stay valid until the next
+ * avr_batch_reset / avr_batch_destroy.  K1 output is the raw encoder output: the caller
+ * applies recode.cpp:1508-1512 (drop a trailing 0x80) and :1354-1360 (tail patch),
+ * see avr_drop_stop_byte / avr_tail_patch. */
+typedef struct avr_batch avr_batch;
+
+avr_batch *avr_batch_create(int device, size_t max_slices, size_t max_bins);
+void       avr_batch_destroy(avr_batch *b);
+int        avr_batch_reset(avr_batch *b);
+
+/* init_states: n_states bytes (2*pStateIdx+valMPS), the slice's cabac_state[] as it was
+ * when the slice's first bin was requested; n_states <= AVR_MAX_STATES and all slices of a
+ * batch use the same n_states.  Returns the slice index (>= 0) or an error (< 0). */
+int avr_batch_add_slice_cabac(avr_batch *b, const uint16_t *recs, size_t n,
+                              const uint8_t *init_states, size_t n_states);
+int avr_batch_add_slice_range(avr_batch *b, const uint16_t *recs, size_t n);
+
+int avr_batch_run(avr_batch *b);
+
+int avr_batch_get(avr_batch *b, size_t slice, const uint8_t **bytes, size_t *len, int *status);
+/* K1 only: the slice's state bytes after its last bin (what cabac_code.h:43-47 leaves in *state). */
+int avr_batch_get_states(avr_batch *b, size_t slice, const uint8_t **states, size_t *n_states);
+/* milliseconds of the last run: [0] H2D, [1] pack kernel, [2] encode kernel, [3] D2H */
+int avr_batch_timings(avr_batch *b, float ms[4]);
+
+/* ------------------------------------------------------------------ device-resident API
+ * All pointers below are DEVICE pointers on `device`; `stream` is a hipStream_t (NULL = the
+ * null stream).  Calls only enqueue work.  These are what the batch API is made of and what
+ * bench.py times with inputs already resident in HBM.
+ *
+ * Slice-major layout: slice i's records are recs[rec_off[i] .. rec_off[i] + n_bins[i]);
+ * rec_off[] entries are multiples of 8 records (16 bytes).
+ *
+ * Wave-interleaved tile layout (what the encode kernels read): slices are taken 64 at a
+ * time in `order` (order[g] = slice handled by lane g%64 of tile g/64).  A tile holds
+ * max-over-its-lanes ceil(n_bins/8) chunks; chunk c of lane l is the 16 bytes at
+ *   tiles + (tile_off[t] + c*64 + l) * 16
+ * so one wave-wide load instruction reads 1 KiB contiguous.  tile_off has n_tiles+1 entries
+ * in units of 16-byte chunks. */
+int avr_pack_tiles_device(int device, void *stream,
+                          const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                          const uint32_t *order, size_t n_slices,
+                          const uint64_t *tile_off, void *tiles);
+
+/* K1.  init_states: n_slices*n_states bytes indexed by slice; out_off: n_slices+1 byte offsets
+ * into out; out_len/status indexed by slice; final_states may be NULL. */
+int avr_cabac_encode_tiles_device(int device, void *stream,
+                                  const void *tiles, const uint64_t *tile_off,
+                                  const uint32_t *n_bins, const uint32_t *order, size_t n_slices,
+                                  const uint8_t *init_states, size_t n_states,
+                                  uint8_t *out, const uint64_t *out_off,
+                                  uint32_t *out_len, int32_t *status, uint8_t *final_states);
+
+/* K2. */
+int avr_range_encode_tiles_device(int device, void *stream,
+                                  const void *tiles, const uint64_t *tile_off,
+                                  const uint32_t *n_bins, const uint32_t *order, size_t n_slices,
+                                  uint8_t *out, const uint64_t *out_off,
+                                  uint32_t *out_len, int32_t *status);
+
+/* Variants that read the slice-major layout directly (one 16-byte load per lane per 8 bins,
+ * uncoalesced across lanes); kept for the layout comparison in DESIGN.md and for tests. */
+int avr_cabac_encode_slices_device(int device, void *stream,
+                                   const uint16_t *recs, const uint64_t *rec_off,
+                                   const uint32_t *n_bins, const uint32_t *order, size_t n_slices,
+                                   const uint8_t *init_states, size_t n_states,
+                                   uint8_t *out, const uint64_t *out_off,
+                                   uint32_t *out_len, int32_t *status, uint8_t *final_states);
+int avr_range_encode_slices_device(int device, void *stream,
+                                   const uint16_t *recs, const uint64_t *rec_off,
+                                   const uint32_t *n_bins, const uint32_t *order, size_t n_slices,
+                                   uint8_t *out, const uint64_t *out_off,
+                                   uint32_t *out_len, int32_t *status);
+
+/* ------------------------------------------------------------------ synthetic bin streams
+ * Seeded generators for the BASELINE.json configurations; the same code
+ * runs on the host (avr_synth_*_host) and on the device so that CPU checks and GPU runs see
+ * identical records.  `workload`: 2 = 1080p30 slices, 3 = ragged "directory of files",
+ * 4 = 4K60 8 slices/frame, 5 = residual-only roofline stress.  `scale_permille` scales the
+ * per-slice length (1000 = the configuration's own size) so tests can run small cases.
+ * Slice i of a run is generated from (seed, first_slice + i) alone, which is what lets ranks
+ * shard a workload without exchanging anything. */
+typedef struct {
+    int      workload;
+    uint32_t scale_permille;
+    uint64_t seed;
+    uint64_t first_slice;
+    uint32_t n_states;       /* out: state bytes per slice this workload declares */
+} avr_synth_config;
+
+int avr_synth_config_init(avr_synth_config *cfg, int workload, uint32_t scale_permille,
+                          uint64_t first_slice);
+/* number of records slice i will have (host; cheap closed loop over the generator) */
+int avr_synth_count_host(const avr_synth_config *cfg, int kind, size_t n_slices, uint32_t *n_bins);
+int avr_synth_generate_host(const avr_synth_config *cfg, int kind, size_t n_slices,
+                            const uint64_t *rec_off, uint16_t *recs, uint8_t *init_states);
+int avr_synth_count_device(int device, void *stream, const avr_synth_config *cfg, int kind,
+                           size_t n_slices, uint32_t *n_bins);
+/* writes straight into the tile layout */
+int avr_synth_generate_tiles_device(int device, void *stream, const avr_synth_config *cfg, int kind,
+                                    size_t n_slices, const uint32_t *order,
+                                    const uint64_t *tile_off, void *tiles, uint8_t *init_states);
+
+/* ------------------------------------------------------------------ host epilogue helpers
+ * decompressor::cabac_decoder::finish (recode.cpp:1508-1512): length after dropping a
+ * trailing 0x80; decompressor::run tail patch (recode.cpp:1354-1360): buf must have room for
+ * len+1 bytes; length_parity -1 = "no patch recorded". */
+size_t avr_drop_stop_byte(const uint8_t *buf, size_t len);
+size_t avr_tail_patch(uint8_t *buf, size_t len, int length_parity, uint8_t last_byte);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVRECODE_MS_AMD_H */
