@@ -111,6 +111,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build_native()
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7; loading it first
+        # makes the dynamic linker bind this library to the same copy (same SONAME), which is
+        # required anyway since device pointers and streams are shared with torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             handle = ctypes.CDLL(LIB_PATH)
         except OSError as exc:

@@ -123,7 +123,7 @@ def test_api_argument_errors(avr):
         with pytest.raises(avr.AvrError, match="not 2\\*pStateIdx"):
             avr.Batch(0, 1, 8).add_slice_cabac(np.array([TERM1]), np.full(8, 200, dtype=np.uint8))
         b.run()
-        assert b.get(0)[0] == b.get(1)[0] == b"\x80"          # a terminate-only slice is the bare stop byte
+        assert b.get(0)[0] == b.get(1)[0] == b"\xfe\x80"      # end_of_slice alone: 7 one bits, 0, stop bit
         b.reset()
         b.add_slice_range(np.array([3 | (1 << 8)], dtype=np.uint16))
         b.run()
