@@ -30,6 +30,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avrecode_ms_amd.h
 KIND_CABAC, KIND_RANGE = 0, 1
 SEL_BYPASS, SEL_TERMINATE = 1024, 1025
 SLICE_OK, SLICE_ZERO_PROB, SLICE_OVERFLOW, SLICE_BAD_RECORD = 0, 1, 2, 3
+NOP_CABAC, NOP_RANGE = 1026 << 1, 0
 
 _SOURCES = ["avr_kernels.hip", "avr_api.cpp"]
 _DEPS = _SOURCES + ["avr_coder.h", "avr_internal.h", "avr_synth.h", "avr_tables.h"]
@@ -84,8 +85,8 @@ SIGNATURES = {
     "avr_batch_get": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
     "avr_batch_get_states": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]),
     "avr_batch_timings": (c_int, [c_void_p, POINTER(c_float)]),
-    "avr_pack_tiles_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                                      c_void_p, c_void_p]),
+    "avr_pack_tiles_device": (c_int, [c_int, c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                      c_void_p, c_void_p, c_void_p]),
     "avr_cabac_encode_tiles_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                               c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "avr_range_encode_tiles_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -216,7 +216,7 @@ static int add_slice(avr_batch *b, int kind, const uint16_t *recs, size_t n, con
         return fail(AVR_ERR_CAPACITY, "batch holds max_bins=%zu records", b->max_bins);
     b->total_bins += n;
     if (n) memcpy(b->h_recs.p + off, recs, n * sizeof(uint16_t));
-    if (padded > n) memset(b->h_recs.p + off + n, 0, (padded - n) * sizeof(uint16_t));
+    for (uint64_t i = n; i < padded; i++) b->h_recs.p[off + i] = kind == AVR_KIND_CABAC ? AVR_NOP_CABAC : AVR_NOP_RANGE;
     b->rec_off.push_back(off + padded);
     b->n_bins.push_back(uint32_t(n));
     b->kind = kind;
@@ -274,7 +274,9 @@ int avr_batch_run(avr_batch *b) {
     if (cabac && ns) AVR_HIP(hipMemcpyAsync(b->d_states.p, b->h_states.p, n * ns, hipMemcpyHostToDevice, s));
     // the vectors above are pageable: the copies have been staged by the runtime when the calls return
     AVR_HIP(hipEventRecord(b->ev[1], s));
-    AVR_HIP(avr::launch_pack_tiles(s, b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_tile_off.p, b->d_tiles.p));
+    AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
+    AVR_HIP(avr::launch_pack_tiles(s, b->kind, uint32_t(ns), b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, b->d_order.p, n32,
+                                   b->d_tile_off.p, b->d_tiles.p, b->d_status.p));
     AVR_HIP(hipEventRecord(b->ev[2], s));
     if (cabac)
         AVR_HIP(avr::launch_cabac_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_states.p,
@@ -336,11 +338,16 @@ static int check_common(const void *a, const void *b, const void *c, size_t n_sl
     return AVR_OK;
 }
 
-int avr_pack_tiles_device(int device, void *stream, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
-                          const uint32_t *order, size_t n_slices, const uint64_t *tile_off, void *tiles) {
+int avr_pack_tiles_device(int device, void *stream, int kind, size_t n_states, const uint16_t *recs, const uint64_t *rec_off,
+                          const uint32_t *n_bins, const uint32_t *order, size_t n_slices, const uint64_t *tile_off, void *tiles,
+                          int32_t *status) {
     if (int rc = check_common(rec_off, n_bins, tile_off, n_slices)) return rc;
+    if (kind != AVR_KIND_CABAC && kind != AVR_KIND_RANGE) return fail(AVR_ERR_INVALID, "kind %d", kind);
+    if (n_states > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "n_states %zu > %d", n_states, AVR_MAX_STATES);
+    if (n_slices && !status) return fail(AVR_ERR_INVALID, "null status");
     if (int rc = select_device(device)) return rc;
-    AVR_HIP(avr::launch_pack_tiles(static_cast<hipStream_t>(stream), recs, rec_off, n_bins, order, uint32_t(n_slices), tile_off, tiles));
+    AVR_HIP(avr::launch_pack_tiles(static_cast<hipStream_t>(stream), kind, uint32_t(n_states), recs, rec_off, n_bins, order,
+                                   uint32_t(n_slices), tile_off, tiles, status));
     return AVR_OK;
 }
 

@@ -6,6 +6,12 @@
 
 #include "../../include/avrecode_ms_amd.h"
 
+// No-op records: what the packer and the generators pad a slice's last chunk (and a tile's
+// shorter lanes) with, so the encode kernels never test a record index against n_bins.
+//   K1: selector 1026, bin 0 -> r1 = 0, symbol 0: low, range and states unchanged
+//   K2: pos = neg = 0 (never valid in a real record) -> skipped
+#define AVR_NOP_CABAC2  (AVR_NOP_CABAC | (AVR_NOP_CABAC << 16))
+
 namespace avr {
 
 hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,
@@ -17,9 +23,9 @@ hipError_t launch_range_encode(bool tiled, hipStream_t s, const void *recs, cons
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
                                uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
                                int32_t *status);
-hipError_t launch_pack_tiles(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off,
-                             const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
-                             const uint64_t *tile_off, void *tiles);
+hipError_t launch_pack_tiles(hipStream_t s, int kind, uint32_t n_states, const uint16_t *recs,
+                             const uint64_t *rec_off, const uint32_t *n_bins, const uint32_t *order,
+                             uint32_t n_slices, const uint64_t *tile_off, void *tiles, int32_t *status);
 hipError_t launch_synth_count(hipStream_t s, int workload, uint32_t scale, uint64_t seed,
                               uint64_t first_slice, int kind, uint32_t n_slices, uint32_t *n_bins);
 hipError_t launch_synth_tiles(hipStream_t s, int workload, uint32_t scale, uint64_t seed,

@@ -29,6 +29,7 @@
 namespace avr {
 
 __device__ const CabacTables d_tables = make_cabac_tables();
+constexpr uint32_t kTabDwords = 2 * 136;               // packed table: 128 states + 8 pseudo-states
 
 // ------------------------------------------------------------------ record fetch
 
@@ -49,12 +50,50 @@ struct ChunkSource {
     __device__ __forceinline__ uint4 load(uint32_t c) const { return p[size_t(c) * stride]; }
 };
 
-__device__ __forceinline__ uint32_t chunk_rec(const uint4 &v, int j) {
-    const uint32_t w = j < 2 ? v.x : j < 4 ? v.y : j < 6 ? v.z : v.w;
-    return (j & 1) ? (w >> 16) : (w & 0xffffu);
-}
-
 // ------------------------------------------------------------------ K1
+
+// One CABAC bin (cabac_code.h:33-67 on arithmetic_code.h:106-126), written branch-free up to
+// the renormalisation: every lane does the same LDS read / table read / LDS write whatever
+// kind of bin it holds, so a wave never splits on context-vs-bypass.
+//   * a context bin reads and writes its state byte; any other bin reads and writes the
+//     lane's scratch byte (row `n_rows` of the state area);
+//   * terminate and the no-op record are table rows of their own (pseudo-states 130, 132:
+//     LPS range 2 resp. 0 in every range quarter, valMPS 0), bypass (128) overrides the
+//     table value with range/2.
+// Returns true when the bin was put_terminate(1): the caller stops and runs finish().
+struct CabacLane {
+    RangeEncoder<uint32_t, 32, 16> e;
+    uint32_t lane4;         // 4 * lane: this lane's column in the state dwords
+    uint32_t n_states;
+    uint32_t scratch;       // byte offset of the lane's scratch dword
+
+    __device__ __forceinline__ bool bin(uint32_t rec, const uint2 *tab, uint8_t *st8) {
+        const uint32_t sel = (rec >> 1) & 0x7ffu;
+        const bool is_ctx = sel < n_states;
+        // state byte of (context, lane): dword (sel >> 2, lane), byte sel & 3
+        const uint32_t saddr = is_ctx ? (((sel >> 2) << 8) + (sel & 3) + lane4) : scratch;
+        uint32_t s_mem = st8[saddr];
+        // The empty asm statements pin the two LDS reads where they are written: without them
+        // hipcc sinks each read into a branch on the bin kind (it is only "needed" on one side of
+        // a select), which splits the wave and exposes the full LDS latency behind every branch.
+        asm volatile("" : "+v"(s_mem));
+        const uint32_t s = is_ctx ? (s_mem & 127u) : (2 * sel - 1920);   // 1024 -> 128, 1025 -> 130, 1026 -> 132
+        uint2 ent = tab[s];
+        asm volatile("" : "+v"(ent.x), "+v"(ent.y));
+        // normalize = floor(log2(range / 0x100)) (cabac_code.h:37,59,70-79); range != 0 here
+        const int norm = 23 - __builtin_clz(e.range);
+        const uint32_t q = (e.range >> (norm + 6)) & 3;          // (range_approx & 0x180) >> 7, :39-40
+        const uint32_t r_tab = ((ent.x >> (q * 8)) & 0xffu) << norm;              // :40-41, :60
+        const uint32_t r1 = sel == AVR_SEL_BYPASS ? (e.range >> 1) : r_tab;       // :53
+        const uint32_t sym = (rec ^ s) & 1;                      // :34 (pseudo-states have valMPS 0)
+        const uint32_t r0 = e.range - r1;                        // arithmetic_code.h:107-114
+        e.low += sym ? r0 : 0u;
+        e.range = sym ? r1 : r0;
+        st8[saddr] = uint8_t(sym ? (ent.y >> 8) : ent.y);        // cabac_code.h:43-47
+        if (e.range < 0x200u) e.emit_digit();                    // arithmetic_code.h:115-122 (one digit)
+        return rec == ((AVR_SEL_TERMINATE << 1) | 1);            // cabac_code.h:63-65
+    }
+};
 
 template <bool TILED>
 __global__ __launch_bounds__(64) void k_cabac_encode(
@@ -63,17 +102,21 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
     uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
     uint8_t *final_states) {
     extern __shared__ uint32_t lds[];
-    uint2 *tab = reinterpret_cast<uint2 *>(lds);                 // 128 entries
-    uint32_t *st32 = lds + 256;                                  // state dwords
+    uint2 *tab = reinterpret_cast<uint2 *>(lds);                 // 128 states + pseudo-states 128..135
+    uint32_t *st32 = lds + kTabDwords;                           // state dwords
     uint8_t *st8 = reinterpret_cast<uint8_t *>(st32);
 
     const uint32_t lane = threadIdx.x;
     const uint32_t g = blockIdx.x * 64 + lane;
     for (uint32_t i = lane; i < 128; i += 64)
         tab[i] = make_uint2(d_tables.packed[i][0], d_tables.packed[i][1]);
+    if (lane < 8)                                                // 130: terminate (LPS range 2), others 0
+        tab[128 + lane] = make_uint2(lane == 2 ? 0x02020202u : 0u, 0u);
 
-    const bool active = g < n_slices;
-    const uint32_t slice = active ? (order ? order[g] : g) : 0;
+    const bool in_range = g < n_slices;
+    const uint32_t slice = in_range ? (order ? order[g] : g) : 0;
+    int32_t st = in_range ? status[slice] : AVR_SLICE_OK;       // a slice flagged by the packer is skipped
+    const bool active = in_range && st == AVR_SLICE_OK;
     const uint32_t nb = active ? n_bins[slice] : 0;
     const uint32_t ns4 = (n_states + 3) >> 2;
 
@@ -89,56 +132,43 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
     }
     __syncthreads();
 
-    RangeEncoder<uint32_t, 32, 16> e;
-    const uint64_t o0 = active ? out_off[slice] : 0;
-    const uint32_t cap = active ? uint32_t(out_off[slice + 1] - o0) : 0;
-    e.init(0x7F800000u, out + o0, cap);                          // cabac_code.h:30
-    int32_t st = AVR_SLICE_OK;
+    CabacLane L;
+    const uint64_t o0 = in_range ? out_off[slice] : 0;
+    const uint32_t cap = in_range ? uint32_t(out_off[slice + 1] - o0) : 0;
+    L.e.init(0x7F800000u, out + o0, cap);                        // cabac_code.h:30
+    L.lane4 = lane * 4;
+    L.n_states = n_states;
+    L.scratch = ns4 * 256 + lane * 4;                            // one dword row past the states
 
     const ChunkSource<TILED> src(recs, off, g, slice);
     const uint32_t n_chunks = (nb + 7) >> 3;
-    uint4 cur = n_chunks ? src.load(0) : make_uint4(0, 0, 0, 0);
-    for (uint32_t c = 0; c < n_chunks; c++) {
-        const uint4 nxt = (c + 1 < n_chunks) ? src.load(c + 1) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (c * 8 + j >= nb) break;
-            const uint32_t rec = chunk_rec(cur, j);
-            const uint32_t bin = rec & 1, sel = (rec >> 1) & 0x7ff;
-            if (e.range == 0 || sel > AVR_SEL_TERMINATE || (sel < 1024 && sel >= n_states)) {
-                st = AVR_SLICE_BAD_RECORD;                       // bin after finish(), or bad selector
-                c = n_chunks;
-                break;
-            }
-            const bool is_ctx = sel < 1024;
-            const uint32_t saddr = is_ctx ? (((sel >> 2) * 64 + lane) * 4 + (sel & 3)) : lane * 4;
-            const uint32_t s = is_ctx ? (st8[saddr] & 127u) : 0;
-            const uint2 ent = tab[s];
-            // normalize = floor(log2(range / 0x100)) (cabac_code.h:37,59,70-79)
-            const int norm = 23 - __clz(e.range);
-            const uint32_t q = (e.range >> (norm + 6)) & 3;      // (range_approx & 0x180) >> 7, :39-40
-            const uint32_t rlps = ((ent.x >> (q * 8)) & 0xff) << norm;           // :40-41
-            const uint32_t r1 = is_ctx ? rlps                                    // :35
-                              : (sel == AVR_SEL_BYPASS ? (e.range >> 1)          // :53
-                                                       : (2u << norm));          // :60
-            const uint32_t sym = is_ctx ? (bin ^ (s & 1)) : bin;                 // :34
-            // arithmetic_code.h:107-114
-            const uint32_t r0 = e.range - r1;
-            e.low += sym ? r0 : 0;
-            e.range = sym ? r1 : r0;
-            if (is_ctx) st8[saddr] = uint8_t(sym ? (ent.y >> 8) : ent.y);        // cabac_code.h:43-47
-            if (e.range < 0x200u) e.emit_digit();                // arithmetic_code.h:115-122 (one digit)
-            if (sel == AVR_SEL_TERMINATE && bin) e.finish();     // cabac_code.h:63-65
+    const uint4 nop4 = make_uint4(AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2);
+    uint4 cur = n_chunks > 0 ? src.load(0) : nop4;
+    uint4 nx1 = n_chunks > 1 ? src.load(1) : nop4;
+    uint32_t term_at = 0xffffffffu;                              // record index of put_terminate(1)
+    for (uint32_t c = 0; c < n_chunks && term_at == 0xffffffffu; c++) {
+        const uint4 nx2 = (c + 2 < n_chunks) ? src.load(c + 2) : nop4;
+        uint32_t w0 = cur.x, w1 = cur.y, w2 = cur.z, w3 = cur.w;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t d = w0;
+            w0 = w1; w1 = w2; w2 = w3;
+            if (L.bin(d & 0xffffu, tab, st8)) { term_at = c * 8 + 2 * k; break; }
+            if (L.bin(d >> 16, tab, st8)) { term_at = c * 8 + 2 * k + 1; break; }
         }
-        cur = nxt;
+        cur = nx1;
+        nx1 = nx2;
     }
-    if (active) {
-        if (e.range != 0 && st == AVR_SLICE_OK) e.finish();      // ~encoder(), arithmetic_code.h:100
-        e.w.flush();
-        if (st == AVR_SLICE_OK && e.w.n > cap) st = AVR_SLICE_OVERFLOW;
-        out_len[slice] = e.w.n;
+    if (in_range) {
+        if (active) {
+            if (term_at != 0xffffffffu && term_at + 1 < nb) st = AVR_SLICE_BAD_RECORD;   // a bin after finish()
+            else L.e.finish();                                   // cabac_code.h:63-65 / ~encoder(), arithmetic_code.h:100
+            L.e.w.flush();
+            if (st == AVR_SLICE_OK && L.e.w.n > cap) st = AVR_SLICE_OVERFLOW;
+        }
+        out_len[slice] = active ? L.e.w.n : 0;
         status[slice] = st;
-        if (final_states) {
+        if (final_states && active) {
             uint8_t *dst = final_states + size_t(slice) * n_states;
             for (uint32_t k = 0; k < ns4; k++) {
                 const uint32_t v = st32[k * 64 + lane];
@@ -151,59 +181,87 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
 
 // ------------------------------------------------------------------ K2
 
+// floor(n / d) for n < 2^63 + 1, 2 <= d < 256, by long division over 16-bit digits: each step
+// divides a 24-bit value by d with one multiply-high by m = ceil(2^32 / d), exact because
+// a * (m*d - 2^32) < 2^32 for a < 2^24, d < 2^8.  (The GPU has no integer divide.)
+__device__ __forceinline__ uint64_t div_u64_small(uint64_t n, uint32_t d, uint32_t m) {
+    const uint32_t hi = uint32_t(n >> 32), lo = uint32_t(n);
+    uint32_t a = hi >> 16;
+    const uint32_t q3 = __umulhi(a, m); a = ((a - q3 * d) << 16) | (hi & 0xffffu);
+    const uint32_t q2 = __umulhi(a, m); a = ((a - q2 * d) << 16) | (lo >> 16);
+    const uint32_t q1 = __umulhi(a, m); a = ((a - q1 * d) << 16) | (lo & 0xffffu);
+    const uint32_t q0 = __umulhi(a, m);
+    return (uint64_t((q3 << 16) | q2) << 32) | ((q1 << 16) | q0);
+}
+
 template <bool TILED>
 __global__ __launch_bounds__(64) void k_range_encode(
     const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
     uint32_t n_slices, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
+    __shared__ uint32_t magic[256];                              // ceil(2^32 / d)
     const uint32_t lane = threadIdx.x;
+    for (uint32_t d = lane; d < 256; d += 64) magic[d] = d >= 2 ? 0xffffffffu / d + 1 : 0;
+    __syncthreads();
     const uint32_t g = blockIdx.x * 64 + lane;
     if (g >= n_slices) return;
     const uint32_t slice = order ? order[g] : g;
-    const uint32_t nb = n_bins[slice];
+    int32_t st = status[slice];
+    const bool active = st == AVR_SLICE_OK;
+    const uint32_t nb = active ? n_bins[slice] : 0;
 
     RangeEncoder<uint64_t, 64, 8> e;
     const uint64_t o0 = out_off[slice];
     const uint32_t cap = uint32_t(out_off[slice + 1] - o0);
     e.init(uint64_t(1) << 63, out + o0, cap);                    // arithmetic_code.h:96-97
-    int32_t st = AVR_SLICE_OK;
 
     const ChunkSource<TILED> src(recs, off, g, slice);
     const uint32_t n_chunks = (nb + 7) >> 3;
-    uint4 cur = n_chunks ? src.load(0) : make_uint4(0, 0, 0, 0);
-    for (uint32_t c = 0; c < n_chunks; c++) {
-        const uint4 nxt = (c + 1 < n_chunks) ? src.load(c + 1) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (c * 8 + j >= nb) break;
-            const uint32_t rec = chunk_rec(cur, j);
+    const uint4 nop4 = make_uint4(0, 0, 0, 0);
+    uint4 cur = n_chunks > 0 ? src.load(0) : nop4;
+    uint4 nx1 = n_chunks > 1 ? src.load(1) : nop4;
+    bool dead = false;
+    for (uint32_t c = 0; c < n_chunks && !dead; c++) {
+        const uint4 nx2 = (c + 2 < n_chunks) ? src.load(c + 2) : nop4;
+        uint32_t w0 = cur.x, w1 = cur.y, w2 = cur.z, w3 = cur.w;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8 && !dead; k++) {
+            const uint32_t rec = w0 & 0xffffu;
+            w0 = (w0 >> 16) | (w1 << 16); w1 = (w1 >> 16) | (w2 << 16); w2 = (w2 >> 16) | (w3 << 16); w3 >>= 16;
             const uint32_t bin = rec & 1, pos = (rec >> 1) & 0x7f, neg = (rec >> 8) & 0x7f;
             const uint32_t total = pos + neg;                    // recode.cpp:825
-            if (total == 0) { st = AVR_SLICE_BAD_RECORD; c = n_chunks; break; }
-            const uint64_t r1 = (e.range / total) * pos;         // recode.cpp:826
+            if (total == 0) continue;                            // no-op (padding) record
+            const uint64_t quot = total == 1 ? e.range : div_u64_small(e.range, total, magic[total]);
+            const uint64_t r1 = quot * pos;                      // recode.cpp:826
             const uint64_t r0 = e.range - r1;                    // arithmetic_code.h:108
             e.low += bin ? r0 : 0;
             e.range = bin ? r1 : r0;
             if (e.range < (uint64_t(1) << 51)) {                 // min_range, arithmetic_code.h:61-62,115
-                if (e.range == 0) { st = AVR_SLICE_ZERO_PROB; c = n_chunks; break; }   // :116-118
-                while (e.range < (uint64_t(1) << 55)) e.emit_digit();                  // :120-122
+                if (e.range == 0) { st = AVR_SLICE_ZERO_PROB; dead = true; }           // :116-118
+                else do e.emit_digit(); while (e.range < (uint64_t(1) << 55));         // :120-122
             }
         }
-        cur = nxt;
+        cur = nx1;
+        nx1 = nx2;
     }
-    if (st == AVR_SLICE_OK) e.finish();                          // recode.cpp:1100
-    e.w.flush();
-    if (st == AVR_SLICE_OK && e.w.n > cap) st = AVR_SLICE_OVERFLOW;
-    out_len[slice] = e.w.n;
+    if (active) {
+        if (st == AVR_SLICE_OK) e.finish();                      // recode.cpp:1100
+        e.w.flush();
+        if (st == AVR_SLICE_OK && e.w.n > cap) st = AVR_SLICE_OVERFLOW;
+    }
+    out_len[slice] = active ? e.w.n : 0;
     status[slice] = st;
 }
 
 // ------------------------------------------------------------------ pack: slice-major -> tiles
 
 // One workgroup (64 lanes) per tile.  Lane l copies the chunks of its slice; a wave-wide
-// store instruction writes 1 KiB contiguous.  Chunks past a short slice's end are zeroed.
+// store instruction writes 1 KiB contiguous.  Records past a slice's end become no-op records.
+// Every record passes through here exactly once, so this is also where selectors are
+// validated: a slice with a record the coders cannot take gets status AVR_SLICE_BAD_RECORD and
+// is skipped by the encode kernel (status must be zeroed by the caller beforehand).
 __global__ __launch_bounds__(64) void k_pack_tiles(
-    const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins, const uint32_t *order,
-    uint32_t n_slices, const uint64_t *tile_off, uint4 *tiles) {
+    int kind, uint32_t n_states, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+    const uint32_t *order, uint32_t n_slices, const uint64_t *tile_off, uint4 *tiles, int32_t *status) {
     const uint32_t lane = threadIdx.x, t = blockIdx.x;
     const uint32_t g = t * 64 + lane;
     const bool active = g < n_slices;
@@ -213,22 +271,33 @@ __global__ __launch_bounds__(64) void k_pack_tiles(
     const uint32_t tile_chunks = uint32_t((tile_off[t + 1] - tile_off[t]) >> 6);
     const uint4 *src = reinterpret_cast<const uint4 *>(recs + (active ? rec_off[slice] : 0));
     uint4 *dst = tiles + tile_off[t] + lane;
+    const uint32_t nop = kind == AVR_KIND_CABAC ? AVR_NOP_CABAC : AVR_NOP_RANGE;
+    const uint32_t nop2 = nop | (nop << 16);
+    bool bad = false;
     for (uint32_t c = 0; c < tile_chunks; c++) {
-        uint4 v = make_uint4(0, 0, 0, 0);
+        uint4 v = make_uint4(nop2, nop2, nop2, nop2);
         if (c < my_chunks) {
             v = src[c];
-            const uint32_t valid = nb - c * 8;                   // records valid in this chunk
-            if (valid < 8) {                                     // zero the padding records
-                uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                for (uint32_t k = 0; k < 4; k++) {
-                    if (2 * k >= valid) w[k] = 0;
-                    else if (2 * k + 1 >= valid) w[k] &= 0xffffu;
+            const uint32_t valid = nb - c * 8;                   // records valid in this chunk (>= 1)
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                uint32_t r = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                if (k >= valid) {
+                    r = nop;
+                } else if (kind == AVR_KIND_CABAC) {
+                    const uint32_t sel = r >> 1;                 // bit 12..15 must be clear too
+                    bad |= !(sel < n_states || sel == AVR_SEL_BYPASS || sel == AVR_SEL_TERMINATE);
+                } else {
+                    bad |= (r & 0x8000u) || ((r >> 1) & 0x7f) + ((r >> 8) & 0x7f) == 0;
                 }
-                v = make_uint4(w[0], w[1], w[2], w[3]);
+                w[k >> 1] = (k & 1) ? ((w[k >> 1] & 0xffffu) | (r << 16)) : ((w[k >> 1] & 0xffff0000u) | r);
             }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
         dst[size_t(c) * 64] = v;
     }
+    if (active && bad) status[slice] = AVR_SLICE_BAD_RECORD;
 }
 
 // ------------------------------------------------------------------ compact: per-slice regions -> dense
@@ -250,21 +319,24 @@ __global__ __launch_bounds__(64) void k_compact(const uint8_t *out, const uint64
 struct TileRecordSink {               // gathers 8 records, stores one 16-byte chunk
     uint4 *dst;                       // chunk 0 of this lane
     uint32_t n;
+    uint32_t nop2;                    // two no-op records (padding)
     uint32_t w[4];
-    __device__ explicit TileRecordSink(uint4 *d) : dst(d), n(0) { w[0] = w[1] = w[2] = w[3] = 0; }
+    __device__ TileRecordSink(uint4 *d, uint32_t nop) : dst(d), n(0), nop2(nop | (nop << 16)) {
+        w[0] = w[1] = w[2] = w[3] = nop2;
+    }
     __device__ void put_record(uint16_t rec) {
-        const uint32_t j = n & 7;
-        w[j >> 1] |= uint32_t(rec) << ((j & 1) * 16);
+        const uint32_t j = n & 7, sh = (j & 1) * 16;
+        w[j >> 1] = (w[j >> 1] & ~(0xffffu << sh)) | (uint32_t(rec) << sh);
         n++;
         if ((n & 7) == 0) {
             dst[size_t((n >> 3) - 1) * 64] = make_uint4(w[0], w[1], w[2], w[3]);
-            w[0] = w[1] = w[2] = w[3] = 0;
+            w[0] = w[1] = w[2] = w[3] = nop2;
         }
     }
     __device__ void flush(uint32_t tile_chunks) {
         uint32_t c = n >> 3;
         if (n & 7) { dst[size_t(c) * 64] = make_uint4(w[0], w[1], w[2], w[3]); c++; }
-        for (; c < tile_chunks; c++) dst[size_t(c) * 64] = make_uint4(0, 0, 0, 0);
+        for (; c < tile_chunks; c++) dst[size_t(c) * 64] = make_uint4(nop2, nop2, nop2, nop2);
     }
 };
 
@@ -287,7 +359,7 @@ __global__ __launch_bounds__(64) void k_synth_tiles(
     const uint32_t lane = threadIdx.x, t = blockIdx.x;
     const uint32_t g = t * 64 + lane;
     const uint32_t tile_chunks = uint32_t((tile_off[t + 1] - tile_off[t]) >> 6);
-    TileRecordSink rs(tiles + tile_off[t] + lane);
+    TileRecordSink rs(tiles + tile_off[t] + lane, kind == AVR_KIND_CABAC ? AVR_NOP_CABAC : AVR_NOP_RANGE);
     if (g < n_slices) {
         const uint32_t slice = order ? order[g] : g;
         if (kind == AVR_KIND_CABAC) {
@@ -308,7 +380,7 @@ __global__ __launch_bounds__(64) void k_synth_tiles(
 
 static inline uint32_t cabac_lds_bytes(uint32_t n_states) {
     const uint32_t rows = (n_states + 3) / 4;
-    return 1024 + 64 * 4 * (rows ? rows : 1);          // row 0 is also the dummy read of non-context bins
+    return kTabDwords * 4 + 64 * 4 * (rows + 1);       // table + state rows + one scratch row
 }
 
 hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,
@@ -345,13 +417,13 @@ hipError_t launch_range_encode(bool tiled, hipStream_t s, const void *recs, cons
     return hipGetLastError();
 }
 
-hipError_t launch_pack_tiles(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off,
-                             const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
-                             const uint64_t *tile_off, void *tiles) {
+hipError_t launch_pack_tiles(hipStream_t s, int kind, uint32_t n_states, const uint16_t *recs,
+                             const uint64_t *rec_off, const uint32_t *n_bins, const uint32_t *order,
+                             uint32_t n_slices, const uint64_t *tile_off, void *tiles, int32_t *status) {
     if (n_slices == 0) return hipSuccess;
     const dim3 grid((n_slices + 63) / 64), block(64);
-    hipLaunchKernelGGL(k_pack_tiles, grid, block, 0, s, recs, rec_off, n_bins, order, n_slices, tile_off,
-                       reinterpret_cast<uint4 *>(tiles));
+    hipLaunchKernelGGL(k_pack_tiles, grid, block, 0, s, kind, n_states, recs, rec_off, n_bins, order, n_slices,
+                       tile_off, reinterpret_cast<uint4 *>(tiles), status);
     return hipGetLastError();
 }
 

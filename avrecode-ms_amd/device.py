@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 
-from . import KIND_CABAC, KIND_RANGE, AvrError, SynthConfig, _check, lib
+from . import KIND_CABAC, KIND_RANGE, NOP_CABAC, NOP_RANGE, AvrError, SynthConfig, _check, lib
 
 
 def synth_config(workload: int, scale_permille: int = 1000, first_slice: int = 0) -> SynthConfig:
@@ -111,7 +111,7 @@ class DeviceWorkload:
         padded = (nb.astype(np.int64) + 7) // 8 * 8
         rec_off = np.zeros(n + 1, dtype=np.int64)
         rec_off[1:] = np.cumsum(padded)
-        flat = np.zeros(int(rec_off[-1]) + 8, dtype=np.uint16)
+        flat = np.full(int(rec_off[-1]) + 8, NOP_CABAC if kind == KIND_CABAC else NOP_RANGE, dtype=np.uint16)
         for i, r in enumerate(recs_list):
             flat[rec_off[i]:rec_off[i] + len(r)] = r
         n_states = len(init_states_list[0]) if (kind == KIND_CABAC and init_states_list) else 0
@@ -121,8 +121,10 @@ class DeviceWorkload:
             n_bins = torch.from_numpy(nb).to(dev)
             order, tile_off = plan_tiles(n_bins)
             tiles = torch.empty(max(int(tile_off[-1].item()), 1) * 16, dtype=torch.uint8, device=dev)
-            _check(L.avr_pack_tiles_device(device_index, _stream_ptr(torch), d_flat.data_ptr(), d_off.data_ptr(),
-                                           n_bins.data_ptr(), order.data_ptr(), n, tile_off.data_ptr(), tiles.data_ptr()))
+            pack_status = torch.zeros(n, dtype=torch.int32, device=dev)
+            _check(L.avr_pack_tiles_device(device_index, _stream_ptr(torch), kind, n_states, d_flat.data_ptr(),
+                                           d_off.data_ptr(), n_bins.data_ptr(), order.data_ptr(), n, tile_off.data_ptr(),
+                                           tiles.data_ptr(), pack_status.data_ptr()))
             init = None
             if kind == KIND_CABAC:
                 init = torch.from_numpy(np.concatenate([np.asarray(s, dtype=np.uint8) for s in init_states_list])
@@ -130,6 +132,7 @@ class DeviceWorkload:
             torch.cuda.synchronize(dev)
         w = cls(kind, device_index, n_bins, order, tile_off, tiles, init, n_states)
         w.rec_flat, w.rec_off = d_flat, d_off
+        w.status.copy_(pack_status)
         return w
 
     def encode(self):

@@ -67,6 +67,15 @@ extern "C" {
 #define AVR_SEL_TERMINATE  1025
 #define AVR_MAX_STATES     1024  /* size of libavcodec's per-slice cabac_state[] */
 
+/* No-op records.  Device layouts keep every slice a whole number of 8-record (16-byte)
+ * chunks; the records between a slice's last bin and the chunk end are no-ops, so the encode
+ * kernels never compare a record index with n_bins.  K1: selector 1026 with bin 0 (probability
+ * range 0, symbol 0: low, range and states unchanged).  K2: pos = neg = 0 (never a real
+ * record).  The batch API and avr_pack_tiles_device write them; callers of the slice-major
+ * device entry points must. */
+#define AVR_NOP_CABAC      (1026 << 1)
+#define AVR_NOP_RANGE      0
+
 #define AVR_KIND_CABAC 0         /* K1: cabac::encoder           (cabac_code.h:26-82)   */
 #define AVR_KIND_RANGE 1         /* K2: recoded_code::encoder    (recode.cpp:322-323)   */
 
@@ -123,13 +132,20 @@ int avr_batch_timings(avr_batch *b, float ms[4]);
  *   tiles + (tile_off[t] + c*64 + l) * 16
  * so one wave-wide load instruction reads 1 KiB contiguous.  tile_off has n_tiles+1 entries
  * in units of 16-byte chunks. */
-int avr_pack_tiles_device(int device, void *stream,
+/* Also validates every record (it is the one place each record is read exactly once): a K1
+ * selector that is neither < n_states nor bypass/terminate, or a K2 record with pos+neg = 0 or
+ * bit 15 set, sets status[slice] = AVR_SLICE_BAD_RECORD.  status must be zero-filled before. */
+int avr_pack_tiles_device(int device, void *stream, int kind, size_t n_states,
                           const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
                           const uint32_t *order, size_t n_slices,
-                          const uint64_t *tile_off, void *tiles);
+                          const uint64_t *tile_off, void *tiles, int32_t *status);
 
 /* K1.  init_states: n_slices*n_states bytes indexed by slice; out_off: n_slices+1 byte offsets
- * into out; out_len/status indexed by slice; final_states may be NULL. */
+ * into out, each a multiple of 8; out_len/status indexed by slice; final_states may be NULL.
+ * status is in/out: a slice whose status is already non-zero (set by the packer) is skipped
+ * with out_len 0; otherwise the kernel writes AVR_SLICE_*.  Records are trusted to be valid
+ * (packer / generator output); a selector that is not a context of the slice, bypass or
+ * terminate is treated as a no-op. */
 int avr_cabac_encode_tiles_device(int device, void *stream,
                                   const void *tiles, const uint64_t *tile_off,
                                   const uint32_t *n_bins, const uint32_t *order, size_t n_slices,
@@ -145,7 +161,8 @@ int avr_range_encode_tiles_device(int device, void *stream,
                                   uint32_t *out_len, int32_t *status);
 
 /* Variants that read the slice-major layout directly (one 16-byte load per lane per 8 bins,
- * uncoalesced across lanes); kept for the layout comparison in DESIGN.md and for tests. */
+ * uncoalesced across lanes); kept for the layout comparison in DESIGN.md and for tests.  The
+ * padding records up to each slice's next multiple of 8 must be no-op records. */
 int avr_cabac_encode_slices_device(int device, void *stream,
                                    const uint16_t *recs, const uint64_t *rec_off,
                                    const uint32_t *n_bins, const uint32_t *order, size_t n_slices,

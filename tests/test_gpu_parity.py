@@ -160,10 +160,12 @@ def test_device_synth_and_encode_match_host_and_oracle(avr, oracle, workload, sc
     tiles = w.tiles.cpu().numpy().view(np.uint16).reshape(-1, 8)           # [chunk*64 + lane][8 records]
     for g in range(0, n_slices, max(1, n_slices // 37)):
         s = int(order[g])
-        mine = tiles[int(tile_off[g // 64]) + (g % 64)::64]
+        mine = tiles[int(tile_off[g // 64]) + (g % 64):int(tile_off[g // 64 + 1]):64]
         n_chunks = (int(nb[s]) + 7) // 8
-        want = recs[int(off[s]):int(off[s]) + n_chunks * 8].reshape(-1, 8)
-        assert np.array_equal(mine[:n_chunks], want), f"slot {g} slice {s}"
+        want = recs[int(off[s]):int(off[s]) + n_chunks * 8].copy()
+        want[int(nb[s]):] = avr.NOP_CABAC if kind == 0 else avr.NOP_RANGE       # chunk padding = no-op records
+        assert np.array_equal(mine[:n_chunks], want.reshape(-1, 8)), f"slot {g} slice {s}"
+        assert (mine[n_chunks:] == (avr.NOP_CABAC if kind == 0 else avr.NOP_RANGE)).all()
     w.encode()
     got, status = w.results()
     assert not any(status)
