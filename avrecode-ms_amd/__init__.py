@@ -31,9 +31,10 @@ KIND_CABAC, KIND_RANGE = 0, 1
 SEL_BYPASS, SEL_TERMINATE = 1024, 1025
 SLICE_OK, SLICE_ZERO_PROB, SLICE_OVERFLOW, SLICE_BAD_RECORD = 0, 1, 2, 3
 NOP_CABAC, NOP_RANGE = 1026 << 1, 0
+CHUNK_BINS = 1024
 
-_SOURCES = ["avr_kernels.hip", "avr_api.cpp"]
-_DEPS = _SOURCES + ["avr_coder.h", "avr_internal.h", "avr_synth.h", "avr_tables.h"]
+_SOURCES = ["avr_kernels.hip", "avr_k1p.hip", "avr_api.cpp"]
+_DEPS = _SOURCES + ["avr_coder.h", "avr_internal.h", "avr_k1p.h", "avr_synth.h", "avr_tables.h"]
 
 
 class AvrError(RuntimeError):
@@ -91,6 +92,11 @@ SIGNATURES = {
                                               c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "avr_range_encode_tiles_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    "avr_cabac_chunked_workspace_bytes": (c_size_t, [c_size_t, c_uint64, c_uint32, c_uint64]),
+    "avr_cabac_encode_chunked_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                c_void_p, c_size_t, c_void_p, c_uint64, c_void_p, c_void_p, c_uint32,
+                                                c_void_p, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p]),
     "avr_cabac_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "avr_range_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

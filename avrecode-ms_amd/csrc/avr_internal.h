@@ -11,6 +11,8 @@
 //   K1: selector 1026, bin 0 -> r1 = 0, symbol 0: low, range and states unchanged
 //   K2: pos = neg = 0 (never valid in a real record) -> skipped
 #define AVR_NOP_CABAC2  (AVR_NOP_CABAC | (AVR_NOP_CABAC << 16))
+// transient per-slice status: K1p declined the slice, k_cabac_encode codes it in the same call
+#define AVR_SLICE_RETRY_SERIAL 100
 
 namespace avr {
 
@@ -18,7 +20,7 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
                                const uint8_t *init_states, uint32_t n_states, uint8_t *out,
                                const uint64_t *out_off, uint32_t *out_len, int32_t *status,
-                               uint8_t *final_states);
+                               uint8_t *final_states, int32_t want_status = AVR_SLICE_OK);
 hipError_t launch_range_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
                                uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
@@ -35,5 +37,13 @@ hipError_t launch_synth_tiles(hipStream_t s, int workload, uint32_t scale, uint6
 
 hipError_t launch_compact(hipStream_t s, const uint8_t *out, const uint64_t *out_off, const uint32_t *out_len,
                           const uint64_t *dense_off, uint32_t n_slices, uint8_t *dense);
+
+size_t k1p_workspace_bytes(size_t n_slices, uint64_t res_total, uint32_t total_chunks, uint64_t dig_total);
+hipError_t launch_k1p(hipStream_t s, const void *tiles, const uint64_t *tile_off, const uint32_t *n_bins,
+                      const uint32_t *order, uint32_t n_slices, const uint8_t *init_states, uint32_t n_states,
+                      const uint64_t *res_off, uint64_t res_total, const uint32_t *chunk_base,
+                      const uint32_t *chunk_slice, uint32_t total_chunks, const uint64_t *dig_off,
+                      uint64_t dig_total, void *workspace, uint8_t *out, const uint64_t *out_off,
+                      uint32_t *out_len, int32_t *status, uint8_t *final_states);
 
 }  // namespace avr

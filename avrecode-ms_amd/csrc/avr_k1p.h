@@ -1,0 +1,302 @@
+// K1p: intra-slice parallel CABAC encode (the same bytes as K1, i.e. as cabac::encoder of
+// /root/reference/cabac_code.h:26-82 on arithmetic_code.h, from many lanes per slice).
+//
+// Why a slice can be cut at all.  The reference codes a slice strictly serially
+// (arithmetic_code.h:107-114: every bin narrows [low, low+range)).  But CABAC's arithmetic is
+// exactly decomposable:
+//   (1) context states evolve per context, independent of low/range (cabac_code.h:43-47);
+//       phase A resolves them and rewrites every bin as a one-byte RESOLVED code
+//           c = (s << 1) | bin   context bin coded in state s = 2*pStateIdx + valMPS, s <= 125
+//           252, 253             bypass bin 0 / 1 (the slot of state 126, never a real context
+//                                state: pStateIdx 63 is only reached by put_terminate)
+//           254, 255             state 127 = (pStateIdx 63, valMPS 1) with bin 0 / 1: the table row
+//                                of pStateIdx 63 is "LPS range 2" in every quarter, which is exactly
+//                                put_terminate (cabac_code.h:57-67): terminate(b) is code 255 - b,
+//                                and so is a context bin met at pStateIdx 63 with symbol b
+//       so that for every non-bypass code  symbol = ((c >> 1) ^ c) & 1  and  row = rows[c >> 2];
+//   (2) range, written R << norm with R in [256, 511] (what cabac_code.h:37-41 recomputes per
+//       bin), is a finite-state chain over R that forgets its past at every coded LPS: after
+//       an LPS R is rangeTabLPS[p][q] renormalised, so only the quarter q (2 bits) of the range
+//       before that LPS matters.  A STRETCH runs from just after an LPS to the first LPS at or
+//       past the next multiple of kChunk bins; phase B1 walks every stretch for the 4 possible
+//       entry quarters (they merge within a few bins), phase B2 chains the 4->4 maps per slice
+//       (serial, one table look-up per stretch) and so fixes every stretch's entry range and
+//       its bit position T (total renormalisation shifts before it);
+//   (3) low is a sum of per-bin terms at known bit positions (arithmetic_code.h:110), so phase
+//       C codes each stretch with low = 0 from its true entry range, aligned to the global
+//       16-bit digit grid, and ADDS its digits into a per-slice array of 32-bit digit sums;
+//       phase D adds the carries up once, serially from the last digit, and applies the
+//       reference's finish() (arithmetic_code.h:128-144) to the exact final (low, range).
+//
+// Everything below is `__host__ __device__`: the kernels in avr_k1p.hip are thin per-lane
+// wrappers, and tests/k1p_emul.cpp runs the very same functions on the CPU (test build only).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define AVR_HD __host__ __device__ inline
+#else
+#define AVR_HD inline
+#endif
+
+namespace avr {
+namespace k1p {
+
+constexpr uint32_t kChunk = 1024;              // bins per fixed chunk (one lane of B1 / C)
+constexpr uint32_t kNone = 0xffffffffu;
+constexpr uint32_t kMaxStretch = 16 * kChunk;  // a longer stretch sends the slice to the serial kernel
+constexpr uint32_t kCodeBypass = 252;
+constexpr uint32_t kCodePad = 252;             // padding of a resolved stream's last 16-byte group
+
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+
+AVR_HD int clz32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clz(x);
+#else
+    return x ? __builtin_clz(x) : 32;
+#endif
+}
+
+// ---- resolved codes
+AVR_HD uint32_t code_sym(uint32_t c) { return ((c >> 1) ^ c) & 1u; }
+AVR_HD bool code_is_bypass(uint32_t c) { return (c >> 1) == 126u; }
+// a coded "LPS" (symbol 1 on a non-bypass bin): the range after it depends on q only
+AVR_HD bool code_is_boundary(uint32_t c) { return code_sym(c) && !code_is_bypass(c); }
+// resolved code of put_terminate(b) and of a context bin met in state s (sym = bin ^ valMPS)
+AVR_HD uint32_t code_terminate(uint32_t b) { return 255u - b; }
+AVR_HD uint32_t code_context(uint32_t s, uint32_t bin) { return s >= 126 ? 255u - ((bin ^ s) & 1u) : (s << 1) | bin; }
+
+// Range (9-bit, normalised) right after a boundary bin coded from quarter q, and its shift.
+AVR_HD uint32_t post_lps_range(uint32_t row, uint32_t q, uint32_t *shift) {
+    const uint32_t rl = (row >> (8 * q)) & 0xffu;
+    const uint32_t sh = uint32_t(clz32(rl)) - 23;          // rl << sh in [256, 511]
+    *shift = sh;
+    return rl << sh;
+}
+
+// One bin on the normalised range, branch-free: returns the renormalisation shift it causes
+// (= bits of output).  rows[p] packs rangeTabLPS[p][0..3], one byte per quarter.
+AVR_HD uint32_t step_range(uint32_t c, const uint32_t *rows, uint32_t *R) {
+    const uint32_t row = rows[c >> 2];
+    const uint32_t rl = (row >> (8 * ((*R >> 6) & 3))) & 0xffu;
+    const uint32_t rm = *R - rl;                           // MPS side: range - rLPS
+    const uint32_t shm = rm < 256 ? 1u : 0u;
+    const uint32_t shl = uint32_t(clz32(rl)) - 23;         // LPS side: range = rLPS (cabac_code.h:40-41)
+    const bool byp = code_is_bypass(c), sym = code_sym(c);
+    *R = byp ? *R : (sym ? rl << shl : rm << shm);         // cabac_code.h:52-54: bypass halves the scale only
+    return byp ? 1u : (sym ? shl : shm);
+}
+
+// ------------------------------------------------------------------ phase B1
+
+struct Stretch {
+    uint32_t first;          // index of the boundary bin that opens the stretch (kNone: chunk inactive;
+                             // chunk 0 is always active and starts at bin 0 with R = 510)
+    uint32_t end;            // one past the stretch's last bin
+    uint32_t t_exit[4];      // shifts inside the stretch, per entry quarter
+    uint16_t r_exit[4];      // normalised range after the last bin, per entry quarter
+    uint8_t exit_q;          // quarter seen by the closing boundary bin, 2 bits per entry quarter
+    uint8_t too_long;        // stretch exceeded kMaxStretch: the slice goes to the serial kernel
+    uint8_t pad[2];
+};
+
+// Visit the resolved codes res[from .. n) in order, 16 bytes per load.  f(i, code) returns true
+// to stop.  res must be 16-byte aligned and readable up to the next multiple of 16.
+template <class F>
+AVR_HD void for_codes(const uint8_t *res, uint32_t from, uint32_t n, F &&f) {
+    for (uint32_t base = from & ~15u; base < n; base += 16) {
+        const U4 v = *reinterpret_cast<const U4 *>(res + base);
+        uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t d = w0;
+            w0 = w1; w1 = w2; w2 = w3;
+            const uint32_t i = base + 4 * k;
+            // (i + b - from) < (n - from) is "from <= i + b < n" in one unsigned compare
+            if (i + 0 - from < n - from && f(i + 0, d & 0xffu)) return;
+            if (i + 1 - from < n - from && f(i + 1, (d >> 8) & 0xffu)) return;
+            if (i + 2 - from < n - from && f(i + 2, (d >> 16) & 0xffu)) return;
+            if (i + 3 - from < n - from && f(i + 3, d >> 24)) return;
+        }
+    }
+}
+
+AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const uint32_t *rows, Stretch *o) {
+    const uint32_t lo = chunk * kChunk, limit = lo + kChunk;
+    uint32_t R[4], T[4] = {0, 0, 0, 0};
+    uint32_t i;
+    o->too_long = 0;
+    o->exit_q = 0;
+    o->pad[0] = o->pad[1] = 0;
+    if (chunk == 0) {
+        o->first = 0;                                      // opens at bin 0 with the initial range 510 (cabac_code.h:30)
+        R[0] = R[1] = R[2] = R[3] = 510;
+        i = 0;
+    } else {
+        uint32_t f = kNone;
+        const uint32_t hi = limit < n ? limit : n;
+        for_codes(res, lo, hi, [&](uint32_t idx, uint32_t c) { if (code_is_boundary(c)) { f = idx; return true; } return false; });
+        if (f == kNone) {
+            o->first = kNone; o->end = 0;
+            for (int q = 0; q < 4; q++) { o->t_exit[q] = 0; o->r_exit[q] = 0; }
+            return;
+        }
+        o->first = f;
+        const uint32_t row = rows[res[f] >> 2];
+        for (uint32_t q = 0; q < 4; q++) { uint32_t sh; R[q] = post_lps_range(row, q, &sh); }
+        i = f + 1;
+    }
+    // until the four candidates have merged (a few bins): byte-wise
+    bool closed = false;
+    while (i < n && !(R[0] == R[1] && R[1] == R[2] && R[2] == R[3])) {
+        const uint32_t c = res[i];
+        const bool closing = i >= limit && code_is_boundary(c);
+        if (closing)
+            for (uint32_t q = 0; q < 4; q++) o->exit_q |= uint8_t(((R[q] >> 6) & 3) << (2 * q));
+        for (uint32_t q = 0; q < 4; q++) T[q] += step_range(c, rows, &R[q]);
+        i++;
+        if (closing) { closed = true; break; }
+    }
+    // merged: one range, 16 codes per load
+    uint32_t Rm = R[0], Tm = 0, end = i;
+    if (!closed && i < n) {
+        end = n;
+        for_codes(res, i, n, [&](uint32_t idx, uint32_t c) {
+            const bool closing = idx >= limit && code_is_boundary(c);
+            if (closing) o->exit_q = uint8_t(((Rm >> 6) & 3) * 0x55u);
+            Tm += step_range(c, rows, &Rm);
+            if (closing) { end = idx + 1; return true; }
+            if (idx - lo > kMaxStretch) { o->too_long = 1; end = idx + 1; return true; }
+            return false;
+        });
+        R[0] = R[1] = R[2] = R[3] = Rm;
+    }
+    o->end = end;
+    for (uint32_t q = 0; q < 4; q++) { o->t_exit[q] = T[q] + Tm; o->r_exit[q] = uint16_t(R[q]); }
+}
+
+// ------------------------------------------------------------------ phase B2 (one lane per slice)
+
+struct Entry {               // what phase C needs per active stretch
+    uint32_t t_start;        // shifts before the stretch = bit position of its first output bit
+    uint32_t q;              // entry quarter
+};
+
+struct SliceTotals {
+    uint32_t t_total;        // shifts over the whole slice
+    uint32_t r_final;        // normalised range after the last bin
+    uint32_t bad;            // 1: a stretch was too long
+    uint32_t pad;
+};
+
+AVR_HD void b2_chain(const Stretch *st, uint32_t n_chunks, Entry *en, SliceTotals *tot) {
+    uint32_t T = 0, q = 0, r = 510, bad = 0;
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        if (st[c].first == kNone) continue;
+        en[c].t_start = T;
+        en[c].q = q;
+        T += st[c].t_exit[q];
+        r = st[c].r_exit[q];
+        bad |= st[c].too_long;
+        q = (st[c].exit_q >> (2 * q)) & 3;
+    }
+    tot->t_total = T;
+    tot->r_final = r;
+    tot->bad = bad;
+    tot->pad = 0;
+}
+
+// Number of 16-bit digits the reference has produced (emitted or deferred) after t shifts:
+// its range is R << (22 - t + 16 nd) and a digit is produced whenever that exponent would
+// drop below 1 (min_range 0x200, cabac_code.h:22, arithmetic_code.h:115-122).
+AVR_HD uint32_t ref_digits(uint32_t t) { return t <= 21 ? 0 : (t - 21 + 15) / 16; }
+
+// ------------------------------------------------------------------ phase C (one lane per active stretch)
+
+// Digit sums: 32-bit per 16-bit digit of the slice's code string.  `Adder` supplies
+//   void store(uint32_t digit_index, uint32_t v)   exclusive position, plain store
+//   void add(uint32_t digit_index, uint32_t v)     shared position, atomic add
+// A stretch shares its first two digits with the windows of earlier stretches and its final
+// window (two digits) with later ones; everything between is its own (argument in DESIGN.md).
+template <class Adder>
+AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, uint32_t chunk,
+                      const uint32_t *rows, Adder &S) {
+    uint32_t R, from;
+    if (chunk == 0) { R = 510; from = 0; }
+    else { uint32_t sh; R = post_lps_range(rows[res[st.first] >> 2], en.q, &sh); from = st.first + 1; }
+    const uint32_t phase = en.t_start & 15, g0 = en.t_start >> 4;
+    // local coder in the reference's form, pre-shifted so its digits sit on the global digit grid
+    uint32_t low = 0, range = R << (22 - phase);
+    uint32_t j = 0, prev = 0;                              // digits produced; the last one, held one step
+    for_codes(res, from, st.end, [&](uint32_t, uint32_t c) {
+        const int norm = 23 - clz32(range);                // cabac_code.h:37
+        const uint32_t q = (range >> (norm + 6)) & 3;      // :39-40
+        const uint32_t rt = ((rows[c >> 2] >> (8 * q)) & 0xffu) << norm;   // :40-41, :60
+        const uint32_t r1 = code_is_bypass(c) ? range >> 1 : rt;           // :53
+        const uint32_t r0 = range - r1;                    // arithmetic_code.h:107-114
+        const bool sym = code_sym(c);
+        low += sym ? r0 : 0u;
+        range = sym ? r1 : r0;
+        if (range < 0x200u) {                              // arithmetic_code.h:115-122: one 16-bit digit
+            const uint32_t carry = low >> 31, digit = (low >> 15) & 0xffffu;
+            if (j > 0) {                                   // release the held digit with the carry it just received
+                if (j - 1 < 2) S.add(g0 + j - 1, prev + carry); else S.store(g0 + j - 1, prev + carry);
+            }
+            prev = digit;
+            j++;
+            low = (low & 0x7fffu) << 16;
+            range <<= 16;
+        }
+        return false;
+    });
+    // what is left: the held digit (+ the window's carry bit) and the 31-bit window itself
+    if (j > 0) S.add(g0 + j - 1, prev + (low >> 31));
+    S.add(g0 + j, (low >> 15) & 0xffffu);
+    S.add(g0 + j + 1, (low & 0x7fffu) << 1);
+}
+
+// ------------------------------------------------------------------ phase D (one lane per slice)
+
+// finish() of arithmetic_code<uint32_t,uint16_t,0x200>::encoder (arithmetic_code.h:128-144) on the
+// exact final window.  Returns the carry it sends into the digits and the bytes it appends.
+AVR_HD uint32_t d_finish(uint32_t low, uint32_t range, uint8_t tail[5], uint32_t *carry) {
+    for (uint32_t stop = 1u << 30; stop > 0; stop >>= 1) {         // :131-137
+        const uint32_t x = (low | stop) & ~(stop - 1);
+        if (stop < range && low <= x && x < uint32_t(low + range)) { low = x; break; }
+    }
+    uint32_t n = 0, cy = 0;
+    while (low != 0 && n < 5) {                                    // :139-142
+        if (low >= 0x80000000u) { cy = 1; low -= 0x80000000u; }
+        const uint32_t d = low >> 23;
+        tail[n++] = uint8_t(d);
+        low = (low - (d << 23)) << 8;
+    }
+    *carry = cy;
+    return n;
+}
+
+// S: the slice's digit sums (ref_digits(t_total) + 2 entries are read).  Writes the final byte
+// string to out (capacity cap) and returns its length.
+AVR_HD uint32_t d_slice(const uint32_t *S, const SliceTotals &tot, uint8_t *out, uint32_t cap) {
+    const uint32_t nd = ref_digits(tot.t_total);
+    // the reference's final low: the two window digits, with whatever carry bit they hold
+    const uint32_t low = uint32_t((uint64_t(S[nd]) << 15) + (S[nd + 1] >> 1));
+    const uint32_t range = tot.r_final << (22 - tot.t_total + 16 * nd);
+    uint8_t tail[5];
+    uint32_t carry;
+    const uint32_t n_tail = d_finish(low, range, tail, &carry);
+    for (uint32_t i = nd; i-- > 0;) {                              // add the carries up, last digit first
+        const uint32_t v = S[i] + carry;
+        carry = v >> 16;
+        if (2 * i + 1 < cap) { out[2 * i] = uint8_t(v >> 8); out[2 * i + 1] = uint8_t(v); }
+    }
+    for (uint32_t k = 0; k < n_tail; k++)
+        if (2 * nd + k < cap) out[2 * nd + k] = tail[k];
+    return 2 * nd + n_tail;
+}
+
+}  // namespace k1p
+}  // namespace avr

@@ -28,7 +28,7 @@
 
 namespace avr {
 
-__device__ const CabacTables d_tables = make_cabac_tables();
+static __device__ const CabacTables d_tables = make_cabac_tables();
 constexpr uint32_t kTabDwords = 2 * 136;               // packed table: 128 states + 8 pseudo-states
 
 // ------------------------------------------------------------------ record fetch
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
     const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
     uint32_t n_slices, const uint8_t *init_states, uint32_t n_states,
     uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
-    uint8_t *final_states) {
+    uint8_t *final_states, int32_t want_status) {
     extern __shared__ uint32_t lds[];
     uint2 *tab = reinterpret_cast<uint2 *>(lds);                 // 128 states + pseudo-states 128..135
     uint32_t *st32 = lds + kTabDwords;                           // state dwords
@@ -115,8 +115,11 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
 
     const bool in_range = g < n_slices;
     const uint32_t slice = in_range ? (order ? order[g] : g) : 0;
-    int32_t st = in_range ? status[slice] : AVR_SLICE_OK;       // a slice flagged by the packer is skipped
-    const bool active = in_range && st == AVR_SLICE_OK;
+    // Only slices whose status is `want_status` are coded: AVR_SLICE_OK in the normal case (a slice
+    // flagged by the packer is skipped), AVR_SLICE_RETRY_SERIAL when K1p hands slices back.
+    int32_t st = in_range ? status[slice] : AVR_SLICE_OK;
+    const bool active = in_range && st == want_status;
+    if (active) st = AVR_SLICE_OK;
     const uint32_t nb = active ? n_bins[slice] : 0;
     const uint32_t ns4 = (n_states + 3) >> 2;
 
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
             L.e.w.flush();
             if (st == AVR_SLICE_OK && L.e.w.n > cap) st = AVR_SLICE_OVERFLOW;
         }
-        out_len[slice] = active ? L.e.w.n : 0;
-        status[slice] = st;
+        if (active) { out_len[slice] = L.e.w.n; status[slice] = st; }
+        else if (want_status == AVR_SLICE_OK) out_len[slice] = 0;
         if (final_states && active) {
             uint8_t *dst = final_states + size_t(slice) * n_states;
             for (uint32_t k = 0; k < ns4; k++) {
@@ -387,7 +390,7 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
                                const uint8_t *init_states, uint32_t n_states, uint8_t *out,
                                const uint64_t *out_off, uint32_t *out_len, int32_t *status,
-                               uint8_t *final_states) {
+                               uint8_t *final_states, int32_t want_status) {
     if (n_slices == 0) return hipSuccess;
     const uint32_t lds = cabac_lds_bytes(n_states);
     const dim3 grid((n_slices + 63) / 64), block(64);
@@ -398,7 +401,7 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
         if (err != hipSuccess) return err;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, s, recs, off, n_bins, order, n_slices, init_states,
-                       n_states, out, out_off, out_len, status, final_states);
+                       n_states, out, out_off, out_len, status, final_states, want_status);
     return hipGetLastError();
 }
 

@@ -140,6 +140,40 @@ class DeviceWorkload:
         encode_tiles(self.kind, self.tiles, self.tile_off, self.n_bins, self.order, self.out, self.out_off,
                      self.out_len, self.status, self.init_states, self.n_states, self.final_states, self.device_index)
 
+    def _chunk_plan(self):
+        """Plan arrays and workspace of the intra-slice parallel path (built once, reused)."""
+        import torch
+        from . import CHUNK_BINS
+        if getattr(self, "_plan", None) is None:
+            dev = self.n_bins.device
+            nb = self.n_bins.to(torch.int64)
+            zero = torch.zeros(1, dtype=torch.int64, device=dev)
+            res_off = torch.cat([zero, torch.cumsum((nb + 15) // 16 * 16 + 16, 0)])
+            n_chunks = torch.clamp((nb + CHUNK_BINS - 1) // CHUNK_BINS, min=1)
+            chunk_base = torch.cat([zero, torch.cumsum(n_chunks, 0)])
+            dig_off = torch.cat([zero, torch.cumsum(nb // 2 + 8, 0)])
+            chunk_slice = torch.repeat_interleave(torch.arange(self.n_slices, device=dev), n_chunks).to(torch.int32)
+            res_total, total_chunks, dig_total = int(res_off[-1]), int(chunk_base[-1]), int(dig_off[-1])
+            ws_bytes = lib().avr_cabac_chunked_workspace_bytes(self.n_slices, res_total, total_chunks, dig_total)
+            self._plan = dict(res_off=res_off, chunk_base=chunk_base.to(torch.int32), chunk_slice=chunk_slice,
+                              dig_off=dig_off, res_total=res_total, total_chunks=total_chunks, dig_total=dig_total,
+                              ws=torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev), ws_bytes=ws_bytes)
+        return self._plan
+
+    def encode_chunked(self):
+        """K1 through the intra-slice parallel kernels (same bytes as encode())."""
+        import torch
+        assert self.kind == KIND_CABAC
+        p = self._chunk_plan()
+        ws_ptr = (p["ws"].data_ptr() + 255) // 256 * 256
+        _check(lib().avr_cabac_encode_chunked_device(
+            self.device_index, _stream_ptr(torch), self.tiles.data_ptr(), self.tile_off.data_ptr(), self.n_bins.data_ptr(),
+            self.order.data_ptr(), self.n_slices, self.init_states.data_ptr(), self.n_states,
+            p["res_off"].data_ptr(), p["res_total"], p["chunk_base"].data_ptr(), p["chunk_slice"].data_ptr(),
+            p["total_chunks"], p["dig_off"].data_ptr(), p["dig_total"], ws_ptr, p["ws_bytes"],
+            self.out.data_ptr(), self.out_off.data_ptr(), self.out_len.data_ptr(), self.status.data_ptr(),
+            self.final_states.data_ptr() if self.final_states is not None else None))
+
     def encode_slice_major(self):
         """Same result from the slice-major layout (only for workloads built with from_host)."""
         import torch

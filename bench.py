@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--workload", type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument("--kind", default="cabac", choices=["cabac", "range"])
     ap.add_argument("--slices", type=int, default=0, help="slices per rank (default: the configuration's own count)")
+    ap.add_argument("--path", default="auto", choices=["auto", "serial", "chunked"],
+                    help="K1 mapping: one lane per slice, or the intra-slice parallel kernels (auto: chunked "
+                         "when the batch has too few slices to fill the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -163,6 +166,13 @@ def main():
     first = shard_first_slice(rank, n_slices)
     w = avr.DeviceWorkload.synth(args.workload, n_slices, kind, local_rank, 1000, first)
 
+    path = args.path
+    if path == "auto":        # one lane per slice needs >= ~64 slices per SIMD-wave-slot to fill 256 CUs
+        path = "chunked" if (kind == avr.KIND_CABAC and n_slices < 65536 and w.total_bins // max(n_slices, 1) >= 8192) else "serial"
+    if kind != avr.KIND_CABAC:
+        path = "serial"
+    step = w.encode_chunked if path == "chunked" else w.encode
+
     def sync_all():
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -170,14 +180,14 @@ def main():
             torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        w.encode()
+        step()
     sync_all()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        starts[i].record()               # w.encode() launches on torch's current stream
-        w.encode()
+        starts[i].record()               # the kernels are launched on torch's current stream
+        step()
         ends[i].record()
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -194,7 +204,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{args.kind}_w{args.workload}_s{n_slices}", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(f"{args.kind}_{path}_w{args.workload}_s{n_slices}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -206,10 +216,11 @@ def main():
             "dtype": "u32" if kind == avr.KIND_CABAC else "u64", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[args.workload], "kernel": "K1 cabac_encode" if kind == avr.KIND_CABAC else "K2 range_encode",
                        "slices_per_gpu": n_slices, "bins_per_gpu": w.total_bins, "h264_bytes_per_gpu": out_bytes,
-                       "n_states": w.n_states, "layout": "wave-interleaved tiles", "parallelism": f"slice-sharded x{world}"},
+                       "n_states": w.n_states, "layout": "wave-interleaved tiles", "path": path, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_cabac_encode<tiled>" if kind == avr.KIND_CABAC else "k_range_encode<tiled>",
+                         "kernel": ("k_k1p_* (resolve, b1, b2, zero, c, d)" if path == "chunked" else "k_cabac_encode<tiled>")
+                         if kind == avr.KIND_CABAC else "k_range_encode<tiled>",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
                          "bins_per_s": w.total_bins / (kernel_ms * 1e-3)},
             "slice_status_errors": status_bad,

@@ -160,6 +160,34 @@ int avr_range_encode_tiles_device(int device, void *stream,
                                   uint8_t *out, const uint64_t *out_off,
                                   uint32_t *out_len, int32_t *status);
 
+/* K1, intra-slice parallel form ("K1p", avrecode-ms_amd/csrc/avr_k1p.h): the same bytes as
+ * avr_cabac_encode_tiles_device, produced by many lanes per slice -- for batches of few, long
+ * slices (a 1-slice-per-frame clip), where one lane per slice leaves the chip idle.  A slice is
+ * cut into chunks of AVR_CHUNK_BINS bins; the caller supplies the plan (device arrays):
+ *   res_off[i]     byte offset of slice i's resolved codes in the workspace, multiple of 16,
+ *                  res_off[i+1] - res_off[i] >= roundup16(n_bins[i]) + 16;  res_total = res_off[n]
+ *   chunk_base[i]  first global chunk of slice i; slice i has max(1, ceil(n_bins[i]/AVR_CHUNK_BINS))
+ *                  chunks; total_chunks = chunk_base[n];  chunk_slice[c] = slice of global chunk c
+ *   dig_off[i]     first 32-bit digit sum of slice i, dig_off[i+1] - dig_off[i] >= n_bins[i]/2 + 8;
+ *                  dig_total = dig_off[n]
+ * workspace: avr_cabac_chunked_workspace_bytes(...) bytes of device memory, 256-byte aligned.
+ * Arguments shared with avr_cabac_encode_tiles_device mean the same (status is in/out).  A slice
+ * the scheme declines (no coded LPS for 16 consecutive chunks) is coded by the serial kernel in
+ * the same call. */
+#define AVR_CHUNK_BINS 1024
+size_t avr_cabac_chunked_workspace_bytes(size_t n_slices, uint64_t res_total, uint32_t total_chunks,
+                                         uint64_t dig_total);
+int avr_cabac_encode_chunked_device(int device, void *stream,
+                                    const void *tiles, const uint64_t *tile_off,
+                                    const uint32_t *n_bins, const uint32_t *order, size_t n_slices,
+                                    const uint8_t *init_states, size_t n_states,
+                                    const uint64_t *res_off, uint64_t res_total,
+                                    const uint32_t *chunk_base, const uint32_t *chunk_slice,
+                                    uint32_t total_chunks, const uint64_t *dig_off, uint64_t dig_total,
+                                    void *workspace, size_t workspace_bytes,
+                                    uint8_t *out, const uint64_t *out_off,
+                                    uint32_t *out_len, int32_t *status, uint8_t *final_states);
+
 /* Variants that read the slice-major layout directly (one 16-byte load per lane per 8 bins,
  * uncoalesced across lanes); kept for the layout comparison in DESIGN.md and for tests.  The
  * padding records up to each slice's next multiple of 8 must be no-op records. */

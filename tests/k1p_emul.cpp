@@ -1,0 +1,73 @@
+// TEST BUILD ONLY.  Runs the product's K1p per-lane functions (avrecode-ms_amd/csrc/avr_k1p.h,
+// the same code the HIP kernels wrap) sequentially on the CPU, so the parallel algorithm can be
+// checked against the oracle in the build container, which has no GPU.  Not part of the product
+// library and not a CPU path of it: nothing ships or links this file.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "avr_k1p.h"
+#include "avr_tables.h"
+
+using namespace avr;
+using namespace avr::k1p;
+
+namespace {
+constexpr CabacTables kT = make_cabac_tables();
+struct HostAdder {
+    std::vector<uint32_t> &S;
+    void store(uint32_t i, uint32_t v) { S[i] = v; stores++; }
+    void add(uint32_t i, uint32_t v) { S[i] += v; adds++; }
+    size_t stores = 0, adds = 0;
+};
+}  // namespace
+
+extern "C" {
+
+// Phase A, serial: K1 records + initial states -> resolved codes.  Returns 0, or 3 (bad record).
+int k1p_emul_resolve(const uint16_t *recs, size_t n, uint8_t *states, size_t n_states, uint8_t *res, size_t *n_res) {
+    size_t m = 0;
+    bool done = false;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t bin = recs[i] & 1, sel = (recs[i] >> 1) & 0x7ff;
+        if (done) return 3;
+        if (sel < 1024) {
+            if (sel >= n_states) return 3;
+            const uint32_t s = states[sel];
+            res[m++] = uint8_t(code_context(s, bin));
+            states[sel] = (bin != (s & 1)) ? kT.mlps_state[127 - s] : kT.mlps_state[128 + s];
+        } else if (sel == 1024) res[m++] = uint8_t(kCodeBypass | bin);
+        else if (sel == 1025) { res[m++] = uint8_t(code_terminate(bin)); done = bin; }
+        else return 3;
+    }
+    *n_res = m;
+    for (size_t k = m; k % 16; k++) res[k] = uint8_t(kCodePad);
+    return 0;
+}
+
+// Phases B1, B2, C, D on resolved codes.  info (optional, 8 words): n_active, t_total, r_final, bad,
+// plain stores, atomic adds, n_digits, -.
+size_t k1p_emul_encode_resolved(const uint8_t *res, size_t n, uint8_t *out, size_t cap, uint32_t *info) {
+    uint32_t rows[64];
+    for (int p = 0; p < 64; p++) rows[p] = kT.packed[2 * p][0];
+    const uint32_t n_chunks = n ? uint32_t((n + kChunk - 1) / kChunk) : 1;
+    std::vector<Stretch> st(n_chunks);
+    std::vector<Entry> en(n_chunks);
+    for (uint32_t c = 0; c < n_chunks; c++) b1_stretch(res, uint32_t(n), c, rows, &st[c]);
+    SliceTotals tot;
+    b2_chain(st.data(), n_chunks, en.data(), &tot);
+    const uint32_t nd = ref_digits(tot.t_total);
+    std::vector<uint32_t> S(nd + 4, 0);
+    HostAdder add{S};
+    uint32_t active = 0;
+    for (uint32_t c = 0; c < n_chunks; c++)
+        if (st[c].first != kNone) { c_stretch(res, st[c], en[c], c, rows, add); active++; }
+    const uint32_t len = d_slice(S.data(), tot, out, uint32_t(cap));
+    if (info) {
+        info[0] = active; info[1] = tot.t_total; info[2] = tot.r_final; info[3] = tot.bad;
+        info[4] = uint32_t(add.stores); info[5] = uint32_t(add.adds); info[6] = nd; info[7] = 0;
+    }
+    return len;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+"""GPU: the intra-slice parallel kernels (K1p, avr_cabac_encode_chunked_device) give the same
+bytes, lengths, statuses and final states as the one-lane-per-slice kernel and the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from test_gpu_parity import compact, host_synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("workload,scale,n_slices", [(2, 40, 70), (4, 100, 40), (5, 1000, 300), (3, 30, 50)])
+def test_chunked_equals_serial_and_oracle(avr, oracle, workload, scale, n_slices):
+    import torch
+    w = avr.DeviceWorkload.synth(workload, n_slices, 0, 0, scale)
+    w.encode()
+    serial, st_serial = w.results()
+    fs_serial = w.final_states.clone()
+    w.out.zero_(); w.out_len.zero_(); w.final_states.zero_()
+    w.encode_chunked()
+    chunked, st_chunked = w.results()
+    assert not any(st_serial) and not any(st_chunked)
+    assert chunked == serial
+    assert torch.equal(w.final_states, fs_serial)
+    cfg, nb, off, recs, states = host_synth(avr, workload, n_slices, 0, scale)
+    want, _ = oracle.encode_batch(0, *compact(recs, off, nb), states, cfg.n_states, threads=8)
+    assert chunked == want
+
+
+def test_chunked_random_and_declined_slices(avr, oracle):
+    rng = np.random.default_rng(55)
+    slices = []
+    for i in range(40):
+        n = int(rng.integers(0, 30000))
+        slices.append(oracle_lib.random_cabac_stream(rng, n, 64, terminate=bool(i % 4)))
+    # slices the scheme declines (no coded LPS for > 16 chunks): must come back right via the serial kernel
+    slices.append(((np.ones(40000, np.uint16) | (1024 << 1)).astype(np.uint16), np.zeros(64, np.uint8)))
+    slices.append((np.ones(60000, np.uint16), np.full(64, 125, np.uint8)))
+    slices.append((np.zeros(0, np.uint16), np.zeros(64, np.uint8)))
+    # a bin after put_terminate(1)
+    bad = np.array([1 | (1025 << 1), 0], dtype=np.uint16)
+    slices.append((bad, np.zeros(64, np.uint8)))
+    w = avr.DeviceWorkload.from_host(0, [r for r, _ in slices], [s for _, s in slices], 0)
+    w.encode_chunked()
+    got, status = w.results()
+    fs = w.final_states.cpu().numpy().reshape(len(slices), 64)
+    for i, (r, s) in enumerate(slices[:-1]):
+        want = oracle.cabac_encode(r, s)
+        assert status[i] == 0 and got[i] == want[0] and fs[i].tobytes() == want[1], f"slice {i} n={len(r)}"
+    assert status[-1] == avr.SLICE_BAD_RECORD
+
+
+def test_chunked_full_size_config2_sampled(avr, oracle):
+    w = avr.DeviceWorkload.synth(2, 512, 0, 0, 1000)
+    w.encode_chunked()
+    got, status = w.results()
+    assert not any(status)
+    for s in (0, 17, 255, 511):
+        cfg, nb, off, recs, states = host_synth(avr, 2, 1, 0, 1000, first=s)
+        want = oracle.cabac_encode(recs[:int(nb[0])], states)
+        assert got[s] == want[0], f"slice {s}"
+    again = w.results()[0]
+    w.out.zero_()
+    w.encode_chunked()
+    assert w.results()[0] == again == got
