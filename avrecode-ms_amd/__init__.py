@@ -31,7 +31,7 @@ KIND_CABAC, KIND_RANGE = 0, 1
 SEL_BYPASS, SEL_TERMINATE = 1024, 1025
 SLICE_OK, SLICE_ZERO_PROB, SLICE_OVERFLOW, SLICE_BAD_RECORD = 0, 1, 2, 3
 NOP_CABAC, NOP_RANGE = 1026 << 1, 0
-CHUNK_BINS = 1024
+CHUNK_BINS, SORT_BLOCK_BINS = 1024, 16384
 
 _SOURCES = ["avr_kernels.hip", "avr_k1p.hip", "avr_api.cpp"]
 _DEPS = _SOURCES + ["avr_coder.h", "avr_internal.h", "avr_k1p.h", "avr_synth.h", "avr_tables.h"]
@@ -59,6 +59,13 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     subprocess.run(cmd, check=True)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
+
+
+class ChunkPlan(ctypes.Structure):
+    """avr_chunk_plan: device arrays of the intra-slice parallel path (include/avrecode_ms_amd.h)."""
+    _fields_ = [("res_off", c_void_p), ("chunk_base", c_void_p), ("chunk_slice", c_void_p), ("blk_base", c_void_p),
+                ("blk_slice", c_void_p), ("dig_off", c_void_p), ("res_total", c_uint64), ("dig_total", c_uint64),
+                ("total_chunks", c_uint32), ("total_blocks", c_uint32)]
 
 
 class SynthConfig(ctypes.Structure):
@@ -92,11 +99,10 @@ SIGNATURES = {
                                               c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "avr_range_encode_tiles_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                               c_void_p, c_void_p, c_void_p, c_void_p]),
-    "avr_cabac_chunked_workspace_bytes": (c_size_t, [c_size_t, c_uint64, c_uint32, c_uint64]),
-    "avr_cabac_encode_chunked_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                                                c_void_p, c_size_t, c_void_p, c_uint64, c_void_p, c_void_p, c_uint32,
-                                                c_void_p, c_uint64, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
-                                                c_void_p, c_void_p]),
+    "avr_cabac_chunked_workspace_bytes": (c_size_t, [c_size_t, c_size_t, c_void_p]),
+    "avr_cabac_encode_chunked_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
+                                                c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p]),
     "avr_cabac_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "avr_range_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
@@ -105,6 +111,8 @@ SIGNATURES = {
     "avr_synth_count_host": (c_int, [POINTER(SynthConfig), c_int, c_size_t, c_void_p]),
     "avr_synth_generate_host": (c_int, [POINTER(SynthConfig), c_int, c_size_t, c_void_p, c_void_p, c_void_p]),
     "avr_synth_count_device": (c_int, [c_int, c_void_p, POINTER(SynthConfig), c_int, c_size_t, c_void_p]),
+    "avr_synth_generate_slices_device": (c_int, [c_int, c_void_p, POINTER(SynthConfig), c_int, c_size_t, c_void_p,
+                                                 c_void_p, c_void_p]),
     "avr_synth_generate_tiles_device": (c_int, [c_int, c_void_p, POINTER(SynthConfig), c_int, c_size_t, c_void_p,
                                                 c_void_p, c_void_p, c_void_p]),
     "avr_drop_stop_byte": (c_size_t, [c_void_p, c_size_t]),

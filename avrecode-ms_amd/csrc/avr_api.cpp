@@ -372,25 +372,25 @@ int avr_range_encode_tiles_device(int device, void *stream, const void *tiles, c
     return AVR_OK;
 }
 
-size_t avr_cabac_chunked_workspace_bytes(size_t n_slices, uint64_t res_total, uint32_t total_chunks, uint64_t dig_total) {
-    return avr::k1p_workspace_bytes(n_slices, res_total, total_chunks, dig_total);
+size_t avr_cabac_chunked_workspace_bytes(size_t n_slices, size_t n_states, const avr_chunk_plan *plan) {
+    if (!plan || n_states > AVR_MAX_STATES) return 0;
+    return avr::k1p_workspace_bytes(n_slices, uint32_t(n_states), plan);
 }
 
-int avr_cabac_encode_chunked_device(int device, void *stream, const void *tiles, const uint64_t *tile_off, const uint32_t *n_bins,
-                                    const uint32_t *order, size_t n_slices, const uint8_t *init_states, size_t n_states,
-                                    const uint64_t *res_off, uint64_t res_total, const uint32_t *chunk_base,
-                                    const uint32_t *chunk_slice, uint32_t total_chunks, const uint64_t *dig_off, uint64_t dig_total,
+int avr_cabac_encode_chunked_device(int device, void *stream, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                                    size_t n_slices, const uint8_t *init_states, size_t n_states, const avr_chunk_plan *plan,
                                     void *workspace, size_t workspace_bytes, uint8_t *out, const uint64_t *out_off,
                                     uint32_t *out_len, int32_t *status, uint8_t *final_states) {
-    if (int rc = check_common(tile_off, n_bins, out_off, n_slices)) return rc;
+    if (int rc = check_common(rec_off, n_bins, out_off, n_slices)) return rc;
     if (n_states > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "n_states %zu > %d", n_states, AVR_MAX_STATES);
-    if (n_slices && (!res_off || !chunk_base || !chunk_slice || !dig_off || !workspace)) return fail(AVR_ERR_INVALID, "null plan pointer");
-    if (workspace_bytes < avr::k1p_workspace_bytes(n_slices, res_total, total_chunks, dig_total))
+    if (!plan || (n_slices && (!plan->res_off || !plan->chunk_base || !plan->chunk_slice || !plan->blk_base || !plan->blk_slice ||
+                               !plan->dig_off || !workspace || !status)))
+        return fail(AVR_ERR_INVALID, "null plan pointer");
+    if (workspace_bytes < avr::k1p_workspace_bytes(n_slices, uint32_t(n_states), plan))
         return fail(AVR_ERR_CAPACITY, "workspace of %zu bytes is smaller than avr_cabac_chunked_workspace_bytes()", workspace_bytes);
     if (int rc = select_device(device)) return rc;
-    AVR_HIP(avr::launch_k1p(static_cast<hipStream_t>(stream), tiles, tile_off, n_bins, order, uint32_t(n_slices), init_states,
-                            uint32_t(n_states), res_off, res_total, chunk_base, chunk_slice, total_chunks, dig_off, dig_total,
-                            workspace, out, out_off, out_len, status, final_states));
+    AVR_HIP(avr::launch_k1p(static_cast<hipStream_t>(stream), recs, rec_off, n_bins, uint32_t(n_slices), init_states,
+                            uint32_t(n_states), plan, workspace, out, out_off, out_len, status, final_states));
     return AVR_OK;
 }
 
@@ -473,6 +473,15 @@ int avr_synth_count_device(int device, void *stream, const avr_synth_config *cfg
     if (int rc = select_device(device)) return rc;
     AVR_HIP(avr::launch_synth_count(static_cast<hipStream_t>(stream), cfg->workload, cfg->scale_permille, cfg->seed, cfg->first_slice,
                                     kind, uint32_t(n_slices), n_bins));
+    return AVR_OK;
+}
+
+int avr_synth_generate_slices_device(int device, void *stream, const avr_synth_config *cfg, int kind, size_t n_slices,
+                                     const uint64_t *rec_off, uint16_t *recs, uint8_t *init_states) {
+    if (!cfg || ((!rec_off || !recs) && n_slices) || n_slices > 0x7fffffffu) return fail(AVR_ERR_INVALID, "bad argument");
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_synth_slices(static_cast<hipStream_t>(stream), cfg->workload, cfg->scale_permille, cfg->seed, cfg->first_slice,
+                                     kind, uint32_t(n_slices), rec_off, recs, init_states, cfg->n_states));
     return AVR_OK;
 }
 

@@ -38,12 +38,13 @@ hipError_t launch_synth_tiles(hipStream_t s, int workload, uint32_t scale, uint6
 hipError_t launch_compact(hipStream_t s, const uint8_t *out, const uint64_t *out_off, const uint32_t *out_len,
                           const uint64_t *dense_off, uint32_t n_slices, uint8_t *dense);
 
-size_t k1p_workspace_bytes(size_t n_slices, uint64_t res_total, uint32_t total_chunks, uint64_t dig_total);
-hipError_t launch_k1p(hipStream_t s, const void *tiles, const uint64_t *tile_off, const uint32_t *n_bins,
-                      const uint32_t *order, uint32_t n_slices, const uint8_t *init_states, uint32_t n_states,
-                      const uint64_t *res_off, uint64_t res_total, const uint32_t *chunk_base,
-                      const uint32_t *chunk_slice, uint32_t total_chunks, const uint64_t *dig_off,
-                      uint64_t dig_total, void *workspace, uint8_t *out, const uint64_t *out_off,
-                      uint32_t *out_len, int32_t *status, uint8_t *final_states);
+size_t k1p_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl);
+hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                      uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
+                      void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
+                      uint8_t *final_states);
+hipError_t launch_synth_slices(hipStream_t s, int workload, uint32_t scale, uint64_t seed, uint64_t first_slice,
+                               int kind, uint32_t n_slices, const uint64_t *rec_off, uint16_t *recs,
+                               uint8_t *init_states, uint32_t n_states);
 
 }  // namespace avr

@@ -1,15 +1,24 @@
 // K1p kernels: intra-slice parallel CABAC encode for batches of few, long slices.
-// The algorithm and its per-lane functions are in avr_k1p.h; this file maps them to lanes:
+// The algorithm and the per-lane functions of phases B-D are in avr_k1p.h; this file maps
+// them to lanes and adds phase A (context-state resolution), which is a per-slice stable
+// counting sort by context followed by one state chain per (slice, context):
 //
-//   k_k1p_resolve   phase A   one lane per slice     records + initial states -> resolved codes
-//   k_k1p_b1        phase B1  one lane per chunk     stretch summaries for the 4 entry quarters
-//   k_k1p_b2        phase B2  one lane per slice     chain the summaries: entry range + bit position
-//   k_k1p_zero                one workgroup per slice zero the digit sums that will be used
-//   k_k1p_c         phase C   one lane per chunk     code each stretch, add its digits
-//   k_k1p_d         phase D   one lane per slice     carries, finish(), bytes
+//   k_k1p_hist      A1  workgroup per sort block    per-block count of every context
+//   k_k1p_scan      A2  workgroup per slice         run start of every context, block offsets
+//   k_k1p_scatter   A3  wave per sort block         stable rank (ballot multisplit) -> sorted order
+//   k_k1p_spec      A4a lane per sorted segment     walk the entered run from the two extreme states
+//   k_k1p_link      A4b lane per sorted segment     true entry state of every segment
+//   k_k1p_chain     A4c lane per sorted segment     state before each bin (cabac_code.h:43-47) -> resolved codes
+//   k_k1p_gather    A5  thread per 4 records        resolved code of every bin, in stream order
+//   k_k1p_b1        B1  lane per chunk              stretch summaries for the 4 entry quarters
+//   k_k1p_b2        B2  lane per slice              chain the summaries: entry range + bit position
+//   k_k1p_zero          workgroup per slice         zero the digit sums that will be used
+//   k_k1p_c         C   lane per chunk              code each stretch, add its digits
+//   k_k1p_d         D   workgroup per slice         finish(), carries (segmented), bytes
 //
-// Results are byte-identical to k_cabac_encode (tests/test_gpu_k1p.py); a slice the scheme
-// cannot take (a stretch with no LPS for 16 chunks) is handed to k_cabac_encode itself.
+// Input is the slice-major record layout (a slice's bins must be consecutive for the sort and
+// for the chunk lanes).  Results are byte-identical to k_cabac_encode (tests/test_gpu_k1p.py);
+// a slice the scheme declines (no coded LPS for 16 chunks) is coded by k_cabac_encode itself.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,96 +32,310 @@ static __device__ const CabacTables d_tables = make_cabac_tables();
 
 using namespace k1p;
 
+constexpr uint32_t kSortBlock = AVR_SORT_BLOCK_BINS;
+
+struct Plan {                       // device pointers of the caller's plan (avr_chunk_plan) + record layout
+    const uint16_t *recs;
+    const uint64_t *rec_off;
+    const uint32_t *n_bins;
+    const uint64_t *res_off;
+    const uint32_t *chunk_base, *chunk_slice;
+    const uint32_t *blk_base, *blk_slice;
+    const uint64_t *dig_off;
+    uint32_t n_states;              // contexts per slice (sort keys)
+};
+
 // ------------------------------------------------------------------ phase A
 
-// One lane per slice, one wave per workgroup; LDS layout as in k_cabac_encode (table, then
-// state dwords (k, lane), then one scratch row).  Reads the tile layout, writes 8 resolved
-// codes (8 bytes) per 8-record chunk.
-__global__ __launch_bounds__(64) void k_k1p_resolve(
-    const uint4 *tiles, const uint64_t *tile_off, const uint32_t *n_bins, const uint32_t *order,
-    uint32_t n_slices, const uint8_t *init_states, uint32_t n_states,
-    uint8_t *res, const uint64_t *res_off, int32_t *status, uint8_t *final_states) {
-    extern __shared__ uint32_t lds[];
-    uint32_t *next = lds;                                        // 136 entries: MPS | LPS << 8 successor
-    uint32_t *st32 = lds + 136;
-    uint8_t *st8 = reinterpret_cast<uint8_t *>(st32);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t g = blockIdx.x * 64 + lane;
-    for (uint32_t i = lane; i < 136; i += 64) next[i] = i < 128 ? d_tables.packed[i][1] : 0;
-
-    const bool in_range = g < n_slices;
-    const uint32_t slice = in_range ? (order ? order[g] : g) : 0;
-    int32_t st = in_range ? status[slice] : AVR_SLICE_OK;
-    const bool active = in_range && st == AVR_SLICE_OK;
-    const uint32_t nb = active ? n_bins[slice] : 0;
-    const uint32_t ns4 = (n_states + 3) >> 2;
-    if (active) {
-        const uint8_t *src = init_states + size_t(slice) * n_states;
-        for (uint32_t k = 0; k < ns4; k++) {
-            uint32_t v = 0;
-            for (uint32_t b = 0; b < 4; b++)
-                if (4 * k + b < n_states) v |= uint32_t(src[4 * k + b]) << (8 * b);
-            st32[k * 64 + lane] = v;
+__global__ __launch_bounds__(256) void k_k1p_hist(Plan p, const int32_t *status, uint32_t *hist) {
+    __shared__ uint32_t cnt[AVR_MAX_STATES];
+    const uint32_t b = blockIdx.x, s = p.blk_slice[b], nk = p.n_states;
+    for (uint32_t k = threadIdx.x; k < nk; k += 256) cnt[k] = 0;
+    __syncthreads();
+    if (status[s] == AVR_SLICE_OK) {
+        const uint32_t n = p.n_bins[s], i0 = (b - p.blk_base[s]) * kSortBlock;
+        const uint32_t i1 = i0 + kSortBlock < n ? i0 + kSortBlock : n;
+        const uint16_t *r = p.recs + p.rec_off[s];
+        for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const uint32_t sel = (r[i] >> 1) & 0x7ffu;
+            if (sel < nk) atomicAdd(&cnt[sel], 1u);
         }
     }
     __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nk; k += 256) hist[size_t(b) * nk + k] = cnt[k];
+}
 
-    const uint32_t lane4 = lane * 4, scratch = ns4 * 256 + lane * 4;
-    const uint4 *src = tiles + tile_off[g >> 6] + (g & 63);
-    uint2 *dst = reinterpret_cast<uint2 *>(res + (in_range ? res_off[slice] : 0));
-    const uint32_t n_chunks = (nb + 7) >> 3;
-    uint32_t term_at = 0xffffffffu;
-    const uint4 nop4 = make_uint4(AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2);
-    uint4 cur = n_chunks > 0 ? src[0] : nop4;
-    for (uint32_t c = 0; c < n_chunks; c++) {
-        const uint4 nxt = (c + 1 < n_chunks) ? src[size_t(c + 1) * 64] : nop4;
-        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-        uint32_t codes[2] = {0, 0};
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t rec = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-            const uint32_t bin = rec & 1, sel = (rec >> 1) & 0x7ffu;
-            const bool is_ctx = sel < n_states;
-            const uint32_t saddr = is_ctx ? (((sel >> 2) << 8) + (sel & 3) + lane4) : scratch;
-            uint32_t s_mem = st8[saddr];
-            asm volatile("" : "+v"(s_mem));                     // keep the LDS read unconditional (see k_cabac_encode)
-            const uint32_t s = is_ctx ? (s_mem & 127u) : 130u;   // 130: any entry >= 128 (successor 0, unused)
-            uint32_t nx = next[s];
-            asm volatile("" : "+v"(nx));
-            const uint32_t sym = (bin ^ s) & 1;
-            st8[saddr] = uint8_t(sym ? (nx >> 8) : nx);          // cabac_code.h:43-47
-            const uint32_t code = is_ctx ? code_context(s, bin)
-                                : sel == AVR_SEL_BYPASS ? (kCodeBypass | bin)
-                                : sel == AVR_SEL_TERMINATE ? code_terminate(bin) : kCodePad;
-            codes[j >> 2] |= code << ((j & 3) * 8);
-            if (rec == ((AVR_SEL_TERMINATE << 1) | 1) && term_at == 0xffffffffu) term_at = c * 8 + j;
-        }
-        dst[c] = make_uint2(codes[0], codes[1]);
-        cur = nxt;
+// hist[b][k] -> position (within the slice's sorted order) of the first bin of context k in block b;
+// run_start[s][k] = first position of context k, run_start[s][nk] = number of context bins.
+__global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, uint32_t *hist, uint32_t *run_start) {
+    __shared__ uint32_t sc[1024];
+    const uint32_t s = blockIdx.x, k = threadIdx.x, nk = p.n_states;
+    const uint32_t b0 = p.blk_base[s], b1 = p.blk_base[s + 1];
+    uint32_t total = 0;
+    if (k < nk)
+        for (uint32_t b = b0; b < b1; b++) total += hist[size_t(b) * nk + k];
+    sc[k] = total;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {                    // inclusive scan over contexts
+        const uint32_t v = k >= d ? sc[k - d] : 0;
+        __syncthreads();
+        sc[k] += v;
+        __syncthreads();
     }
-    if (active) {
-        if (n_chunks & 1) dst[n_chunks] = make_uint2(0xfcfcfcfcu, 0xfcfcfcfcu);   // pad to 16 bytes with kCodePad
-        if (term_at != 0xffffffffu && term_at + 1 < nb) status[slice] = AVR_SLICE_BAD_RECORD;   // a bin after finish()
-        if (final_states) {
-            uint8_t *fs = final_states + size_t(slice) * n_states;
-            for (uint32_t k = 0; k < ns4; k++) {
-                const uint32_t v = st32[k * 64 + lane];
-                for (uint32_t b = 0; b < 4; b++)
-                    if (4 * k + b < n_states) fs[4 * k + b] = uint8_t(v >> (8 * b));
-            }
+    uint32_t run = sc[k] - total;                                // exclusive
+    if (k < nk) {
+        run_start[size_t(s) * (nk + 1) + k] = run;
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint32_t c = hist[size_t(b) * nk + k];
+            hist[size_t(b) * nk + k] = run;
+            run += c;
+        }
+    }
+    if (k == 1023) run_start[size_t(s) * (nk + 1) + nk] = sc[1023];
+}
+
+// One wave per sort block.  Bins are taken 64 at a time in stream order; the lanes holding the
+// same context find each other with one ballot per key bit, which gives every bin its rank among
+// them (stable), and the first of them advances the context's running position.
+__global__ __launch_bounds__(64) void k_k1p_scatter(Plan p, const int32_t *status, const uint32_t *boff,
+                                                    uint8_t *sorted, uint32_t *pos, uint32_t key_bits) {
+    __shared__ uint32_t cnt[AVR_MAX_STATES];
+    const uint32_t b = blockIdx.x, s = p.blk_slice[b], nk = p.n_states, lane = threadIdx.x;
+    if (status[s] != AVR_SLICE_OK) return;
+    for (uint32_t k = lane; k < nk; k += 64) cnt[k] = boff[size_t(b) * nk + k];
+    __syncthreads();
+    const uint32_t n = p.n_bins[s], i0 = (b - p.blk_base[s]) * kSortBlock;
+    const uint32_t i1 = i0 + kSortBlock < n ? i0 + kSortBlock : n;
+    const uint16_t *r = p.recs + p.rec_off[s];
+    uint8_t *so = sorted + p.res_off[s];
+    uint32_t *po = pos + p.res_off[s];
+    const uint64_t lt = (uint64_t(1) << lane) - 1;
+    for (uint32_t base = i0; base < i1; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t rec = i < i1 ? r[i] : uint32_t(AVR_NOP_CABAC);
+        const uint32_t sel = (rec >> 1) & 0x7ffu;
+        const bool is_ctx = sel < nk;
+        uint64_t mask = __ballot(is_ctx);
+        for (uint32_t bit = 0; bit < key_bits; bit++) {
+            const bool one = (sel >> bit) & 1;
+            const uint64_t m = __ballot(one);
+            mask &= one ? m : ~m;
+        }
+        if (is_ctx) {
+            const uint32_t rank = __popcll(mask & lt);
+            const uint32_t start = cnt[sel];
+            const uint32_t at = start + rank;
+            so[at] = uint8_t(rec & 1);
+            po[i] = at;
+            if (rank == 0) cnt[sel] = start + __popcll(mask);
         }
     }
 }
 
-// ------------------------------------------------------------------ phases B1, B2, C, D
+// ---- A4: state chains over the sorted order.
+//
+// The bins of one context are a contiguous run of `sorted`, in stream order; the state before each
+// is a chain from the slice's initial state (cabac_code.h:43-47).  A hot context's run is tens of
+// thousands of bins long, so the sorted order is cut into SEGMENTS of kChunk positions, one lane
+// each.  A run that starts inside a segment starts from its known initial state.  For the run a
+// segment is entered in the middle of, the state is not known yet -- but the CABAC transition
+// functions are MONOTONE in the order
+//     (62,MPS 0) < (61,0) < ... < (0,0) < (0,1) < ... < (62,MPS 1)          [pStateIdx, valMPS]
+// (tests/test_k1p_emul.py checks this on the tables), so if the two extreme states 124 and 125
+// have reached the same state after some bins, every possible state has.  k_k1p_spec walks the
+// entered run from both extremes (and the run it is left in, exactly, if that run started inside);
+// k_k1p_link gives every segment its true entry state (replaying predecessors only where the
+// extremes did not meet, which real streams essentially never do over 1024 bins of one context);
+// k_k1p_chain walks every segment once more and writes the resolved codes.
 
-struct Plan {                       // device pointers of the per-slice / per-chunk plan (see the C ABI)
-    const uint32_t *n_bins;
-    const uint64_t *res_off;        // bytes, multiples of 16
-    const uint32_t *chunk_base;     // first global chunk of each slice (n_slices + 1)
-    const uint32_t *chunk_slice;    // slice of each global chunk
-    const uint64_t *dig_off;        // first digit sum of each slice (n_slices + 1)
+struct Seg {
+    uint32_t k_first;        // context whose run contains the segment's first position
+    uint16_t lo, hi;         // state at the segment's end of the run it is left in, from the extremes
+                             // 124 / 125 (equal: exact); only meaningful if that run goes on
+    uint8_t enters_mid;      // the first position is not the start of its run
+    uint8_t leaves_mid;      // the last position is not the end of its run
+    uint8_t empty;           // no positions
+    uint8_t pad;
 };
+
+__device__ __forceinline__ uint32_t chain_next(const uint32_t *next, uint32_t st, uint32_t bin) {
+    const uint32_t nx = next[st];
+    return ((bin ^ st) & 1) ? (nx >> 8) : (nx & 0xffu);
+}
+
+// Walk sorted positions [from, to) of one run.  WRITE: replace each bin by its resolved code.
+// Two states are carried (for the speculative walk); pass the same value twice for an exact walk.
+template <bool WRITE>
+__device__ __forceinline__ void chain_walk(const uint32_t *next, uint8_t *so, uint32_t from, uint32_t to,
+                                           uint32_t &a, uint32_t &b) {
+    uint32_t at = from;
+    auto one = [&](uint32_t bin) {
+        const uint32_t code = code_context(a, bin);
+        a = chain_next(next, a, bin);
+        if (!WRITE) b = chain_next(next, b, bin);
+        return code;
+    };
+    for (; at < to && (at & 15); at++) { const uint32_t c = one(so[at]); if (WRITE) so[at] = uint8_t(c); }
+    for (; at + 16 <= to; at += 16) {
+        const U4 v = *reinterpret_cast<const U4 *>(so + at);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t sh = (j & 3) * 8;
+            const uint32_t code = one((w[j >> 2] >> sh) & 1u);
+            if (WRITE) w[j >> 2] = (w[j >> 2] & ~(0xffu << sh)) | (code << sh);
+        }
+        if (WRITE) *reinterpret_cast<U4 *>(so + at) = U4{w[0], w[1], w[2], w[3]};
+    }
+    for (; at < to; at++) { const uint32_t c = one(so[at]); if (WRITE) so[at] = uint8_t(c); }
+}
+
+// context whose run [rs[k], rs[k+1]) contains sorted position `at` (at < rs[nk])
+__device__ __forceinline__ uint32_t run_of(const uint32_t *rs, uint32_t nk, uint32_t at) {
+    uint32_t lo = 0, hi = nk;                                    // invariant: rs[lo] <= at < rs[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rs[mid] <= at) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_k1p_spec(Plan p, uint32_t total_chunks, const int32_t *status,
+                                                  const uint32_t *run_start, const uint8_t *init_states,
+                                                  uint8_t *sorted, Seg *seg) {
+    __shared__ uint32_t next[128];
+    if (threadIdx.x < 128) next[threadIdx.x] = d_tables.packed[threadIdx.x][1];
+    __syncthreads();
+    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
+    if (gc >= total_chunks) return;
+    const uint32_t s = p.chunk_slice[gc], nk = p.n_states;
+    Seg o{0, 0, 0, 0, 0, 1, 0};
+    const uint32_t *rs = run_start + size_t(s) * (nk + 1);
+    const uint32_t from = (gc - p.chunk_base[s]) * kChunk;
+    if (status[s] != AVR_SLICE_OK || from >= rs[nk]) { seg[gc] = o; return; }
+    const uint32_t to = from + kChunk < rs[nk] ? from + kChunk : rs[nk];
+    uint8_t *so = sorted + p.res_off[s];
+    const uint8_t *init = init_states + size_t(s) * nk;
+    const uint32_t k0 = run_of(rs, nk, from);
+    o.empty = 0;
+    o.k_first = k0;
+    o.enters_mid = rs[k0] < from;
+    const uint32_t k1 = run_of(rs, nk, to - 1);                 // the run the segment is left in
+    o.leaves_mid = rs[k1 + 1] > to;
+    if (o.leaves_mid) {
+        const uint32_t i0 = init[k1] & 127u;
+        uint32_t a, b;
+        if (k1 == k0 && o.enters_mid && i0 < 126) { a = 124; b = 125; }        // entered and left in the same run
+        else a = b = i0;                                          // the run starts here, or its state never moves
+        if (i0 < 126) chain_walk<false>(next, so, k1 == k0 ? from : rs[k1], to, a, b);
+        o.lo = uint16_t(a);
+        o.hi = uint16_t(b);
+    }
+    seg[gc] = o;
+}
+
+// entry[gc] = state of the run the segment is entered in the middle of, at its first position.
+__global__ __launch_bounds__(256) void k_k1p_link(Plan p, uint32_t total_chunks, const int32_t *status,
+                                                  const uint32_t *run_start, const uint8_t *init_states,
+                                                  uint8_t *sorted, const Seg *seg, uint8_t *entry) {
+    __shared__ uint32_t next[128];
+    if (threadIdx.x < 128) next[threadIdx.x] = d_tables.packed[threadIdx.x][1];
+    __syncthreads();
+    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
+    if (gc >= total_chunks) return;
+    const Seg me = seg[gc];
+    if (me.empty || !me.enters_mid) { entry[gc] = 0; return; }
+    const uint32_t s = p.chunk_slice[gc];
+    // back to the nearest predecessor whose exit is known without its own entry
+    uint32_t j = gc - 1;                                         // c >= 1 because the segment is entered mid-run
+    while (seg[j].lo != seg[j].hi) j--;                          // ends at the latest where the run starts (exact walk)
+    uint32_t st = seg[j].lo;
+    if (j + 1 < gc) {                                            // replay the predecessors whose extremes did not meet
+        uint8_t *so = sorted + p.res_off[s];
+        for (uint32_t r = j + 1; r < gc; r++) {
+            const uint32_t from = (r - p.chunk_base[s]) * kChunk;
+            uint32_t a = st, b = st;
+            chain_walk<false>(next, so, from, from + kChunk, a, b);
+            st = a;
+        }
+    }
+    (void)run_start; (void)init_states; (void)status;
+    entry[gc] = uint8_t(st);
+}
+
+__global__ __launch_bounds__(256) void k_k1p_chain(Plan p, uint32_t total_chunks, const int32_t *status,
+                                                   const uint32_t *run_start, const uint8_t *init_states,
+                                                   uint8_t *sorted, const Seg *seg, const uint8_t *entry,
+                                                   uint8_t *final_states) {
+    __shared__ uint32_t next[128];
+    if (threadIdx.x < 128) next[threadIdx.x] = d_tables.packed[threadIdx.x][1];
+    __syncthreads();
+    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
+    if (gc >= total_chunks) return;
+    const uint32_t s = p.chunk_slice[gc], nk = p.n_states;
+    if (status[s] != AVR_SLICE_OK) return;
+    const uint32_t *rs = run_start + size_t(s) * (nk + 1);
+    const uint8_t *init = init_states + size_t(s) * nk;
+    uint8_t *fin = final_states ? final_states + size_t(s) * nk : nullptr;
+    const uint32_t c = gc - p.chunk_base[s], from = c * kChunk;
+    const Seg me = seg[gc];
+    if (me.empty) {                                              // only segment 0 of a slice without context bins matters
+        if (c == 0 && fin) for (uint32_t k = 0; k < nk; k++) fin[k] = init[k];
+        return;
+    }
+    const uint32_t to = from + kChunk < rs[nk] ? from + kChunk : rs[nk];
+    uint8_t *so = sorted + p.res_off[s];
+    uint32_t k = me.k_first, at = from;
+    uint32_t st = me.enters_mid ? uint32_t(entry[gc]) : (init[k] & 127u);
+    if (c == 0 && fin) for (uint32_t e = 0; e < k; e++) fin[e] = init[e];       // empty runs before the first bin
+    while (at < to) {
+        const uint32_t run_end = rs[k + 1] < to ? rs[k + 1] : to;
+        uint32_t a = st, b = st;
+        chain_walk<true>(next, so, at, run_end, a, b);
+        at = run_end;
+        if (at == rs[k + 1]) {                                   // the run ends here: its final state, then on to the next
+            if (fin) fin[k] = uint8_t(a);
+            k++;
+            while (k < nk && rs[k + 1] == rs[k]) { if (fin) fin[k] = init[k]; k++; }     // contexts without bins
+            if (k < nk) st = init[k] & 127u;
+        }
+    }
+}
+
+// One workgroup (256 threads) per chunk of kChunk bins, 4 consecutive bins per thread: the resolved
+// code of every bin in stream order.  Also the one place every record of this path is examined:
+// a selector that is no context of the slice, bypass or terminate, or a bin after
+// put_terminate(1), flags the slice AVR_SLICE_BAD_RECORD.
+__global__ __launch_bounds__(256) void k_k1p_gather(Plan p, const uint8_t *sorted, const uint32_t *pos,
+                                                    uint8_t *res, int32_t *status) {
+    const uint32_t gc = blockIdx.x, s = p.chunk_slice[gc], nk = p.n_states;
+    if (status[s] != AVR_SLICE_OK) return;
+    const uint32_t n = p.n_bins[s];
+    const uint32_t i = (gc - p.chunk_base[s]) * kChunk + threadIdx.x * 4;
+    if (i >= ((n + 15) & ~15u)) return;
+    const uint16_t *r = p.recs + p.rec_off[s];
+    const uint8_t *so = sorted + p.res_off[s];
+    const uint32_t *po = pos + p.res_off[s];
+    uint32_t codes = 0;
+    bool bad = false;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        uint32_t code = kCodePad;
+        if (i + j < n) {
+            const uint32_t rec = r[i + j], sel = (rec >> 1) & 0x7ffu, bin = rec & 1;
+            if (sel < nk) code = so[po[i + j]];
+            else if (sel == AVR_SEL_BYPASS) code = kCodeBypass | bin;
+            else if (sel == AVR_SEL_TERMINATE) { code = code_terminate(bin); bad |= bin && i + j + 1 < n; }
+            else bad = true;
+            bad |= (rec >> 12) != 0;
+        }
+        codes |= code << (8 * j);
+    }
+    *reinterpret_cast<uint32_t *>(res + p.res_off[s] + i) = codes;
+    if (bad) status[s] = AVR_SLICE_BAD_RECORD;
+}
+
+// ------------------------------------------------------------------ phases B1, B2, C
 
 __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, const uint8_t *res,
                                                 const int32_t *status, Stretch *st) {
@@ -166,62 +389,145 @@ __global__ __launch_bounds__(256) void k_k1p_c(Plan p, uint32_t total_chunks, co
     c_stretch(res + p.res_off[slice], o, en[gc], gc - p.chunk_base[slice], rows, add);
 }
 
-__global__ __launch_bounds__(64) void k_k1p_d(Plan p, uint32_t n_slices, const SliceTotals *tot, const uint32_t *S,
-                                              uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
-                                              int32_t *status) {
-    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= n_slices) return;
-    if (status[s] != AVR_SLICE_OK) { out_len[s] = 0; return; }
-    if (tot[s].bad) { status[s] = AVR_SLICE_RETRY_SERIAL; return; }
+// ------------------------------------------------------------------ phase D
+
+// One workgroup per slice.  Thread 0 applies finish() to the exact final window; then the digit
+// sums are normalised tile by tile from the last digit: each thread adds up kSeg digits with
+// carry-in 0 and reports (carry-out, "all ones"), one thread chains the 256 segments, each
+// thread fixes its segment up, and the bytes go out coalesced.
+constexpr uint32_t kSeg = 33;                  // odd: thread t's digits start at LDS word 33 t (conflict-free)
+constexpr uint32_t kTile = 256 * kSeg;
+
+__global__ __launch_bounds__(256) void k_k1p_d(Plan p, const SliceTotals *tot, const uint32_t *S,
+                                               uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
+                                               int32_t *status) {
+    __shared__ uint32_t dig[kTile];
+    __shared__ uint32_t seg_g[256], seg_p[256], seg_cin[256];
+    __shared__ uint32_t sh_carry;
+    const uint32_t s = blockIdx.x, t = threadIdx.x;
+    if (status[s] != AVR_SLICE_OK) { if (t == 0) out_len[s] = 0; return; }
+    const SliceTotals T = tot[s];
+    if (T.bad) { if (t == 0) status[s] = AVR_SLICE_RETRY_SERIAL; return; }
+    const uint32_t *Ss = S + p.dig_off[s];
+    uint8_t *o = out + out_off[s];
     const uint32_t cap = uint32_t(out_off[s + 1] - out_off[s]);
-    const uint32_t len = d_slice(S + p.dig_off[s], tot[s], out + out_off[s], cap);
-    out_len[s] = len;
-    if (len > cap) status[s] = AVR_SLICE_OVERFLOW;
+    const uint32_t nd = ref_digits(T.t_total);
+    if (t == 0) {
+        const uint32_t low = uint32_t((uint64_t(Ss[nd]) << 15) + (Ss[nd + 1] >> 1));
+        const uint32_t range = T.r_final << (22 - T.t_total + 16 * nd);
+        uint8_t tail[5];
+        uint32_t carry;
+        const uint32_t n_tail = d_finish(low, range, tail, &carry);
+        for (uint32_t k = 0; k < n_tail; k++) {
+            if (2 * nd + k < cap) o[2 * nd + k] = tail[k];
+        }
+        sh_carry = carry;
+        out_len[s] = 2 * nd + n_tail;
+        if (2 * nd + n_tail > cap) status[s] = AVR_SLICE_OVERFLOW;
+    }
+    __syncthreads();
+    uint32_t carry_in = sh_carry;                        // into the last digit of the current tile
+    for (uint32_t hi = nd; hi > 0;) {                    // tiles from the low-order end: digits [lo, hi)
+        const uint32_t lo = hi > kTile ? hi - kTile : 0, cnt = hi - lo;
+        for (uint32_t i = t; i < cnt; i += 256) dig[i] = Ss[lo + i];
+        __syncthreads();
+        // segment t covers tile digits [a, b); the LAST segment (highest t) is the low-order end
+        const uint32_t a = t * kSeg < cnt ? t * kSeg : cnt, b = (t + 1) * kSeg < cnt ? (t + 1) * kSeg : cnt;
+        uint32_t c = 0, all_ones = 1;
+        for (uint32_t i = b; i-- > a;) {
+            const uint32_t v = dig[i] + c;
+            dig[i] = v & 0xffffu;
+            c = v >> 16;
+            all_ones &= (v & 0xffffu) == 0xffffu;
+        }
+        seg_g[t] = c;
+        seg_p[t] = all_ones;
+        __syncthreads();
+        if (t == 0) {
+            uint32_t cin = carry_in;
+            for (uint32_t k = 256; k-- > 0;) {
+                seg_cin[k] = cin;
+                cin = seg_g[k] | (seg_p[k] & cin);       // a carry leaves the segment if it makes one, or passes one on
+            }
+            sh_carry = cin;                              // into the next (higher-order) tile
+        }
+        __syncthreads();
+        if (seg_cin[t]) {
+            for (uint32_t i = b; i-- > a;) {
+                const uint32_t v = dig[i] + 1;
+                dig[i] = v & 0xffffu;
+                if (v <= 0xffffu) break;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < cnt; i += 256) {
+            const uint32_t v = dig[i], at = 2 * (lo + i);
+            if (at + 1 < cap) *reinterpret_cast<uint16_t *>(o + at) = uint16_t((v >> 8) | (v << 8));
+        }
+        carry_in = sh_carry;
+        hi = lo;
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------ launcher
 
-size_t k1p_workspace_bytes(size_t n_slices, uint64_t res_total, uint32_t total_chunks, uint64_t dig_total) {
-    auto up = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
-    return size_t(up(res_total + 16) + up(uint64_t(total_chunks) * sizeof(Stretch)) +
-                  up(uint64_t(total_chunks) * sizeof(Entry)) + up(n_slices * sizeof(SliceTotals)) +
-                  up(dig_total * 4 + 16));
+namespace {
+inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 }
 
-hipError_t launch_k1p(hipStream_t s, const void *tiles, const uint64_t *tile_off, const uint32_t *n_bins,
-                      const uint32_t *order, uint32_t n_slices, const uint8_t *init_states, uint32_t n_states,
-                      const uint64_t *res_off, uint64_t res_total, const uint32_t *chunk_base,
-                      const uint32_t *chunk_slice, uint32_t total_chunks, const uint64_t *dig_off,
-                      uint64_t dig_total, void *workspace, uint8_t *out, const uint64_t *out_off,
-                      uint32_t *out_len, int32_t *status, uint8_t *final_states) {
-    if (n_slices == 0) return hipSuccess;
-    auto up = [](uint64_t x) { return (x + 255) & ~uint64_t(255); };
-    uint8_t *w = static_cast<uint8_t *>(workspace);
-    uint8_t *res = w;                   w += up(res_total + 16);
-    Stretch *st = reinterpret_cast<Stretch *>(w);        w += up(uint64_t(total_chunks) * sizeof(Stretch));
-    Entry *en = reinterpret_cast<Entry *>(w);            w += up(uint64_t(total_chunks) * sizeof(Entry));
-    SliceTotals *tot = reinterpret_cast<SliceTotals *>(w); w += up(n_slices * sizeof(SliceTotals));
-    uint32_t *S = reinterpret_cast<uint32_t *>(w);
-    const Plan p{n_bins, res_off, chunk_base, chunk_slice, dig_off};
+size_t k1p_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl) {
+    return size_t(2 * up256(pl->res_total + 32) + up256(4 * (pl->res_total + 32)) +
+                  up256(uint64_t(pl->total_blocks) * n_states * 4 + 16) + up256(n_slices * uint64_t(n_states + 1) * 4 + 16) +
+                  up256(uint64_t(pl->total_chunks) * sizeof(Seg)) + up256(uint64_t(pl->total_chunks) + 16) +
+                  up256(uint64_t(pl->total_chunks) * sizeof(Stretch)) + up256(uint64_t(pl->total_chunks) * sizeof(Entry)) +
+                  up256(n_slices * sizeof(SliceTotals)) + up256(pl->dig_total * 4 + 16));
+}
 
-    const uint32_t lds = 136 * 4 + 64 * 4 * ((n_states + 3) / 4 + 1);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_k1p_resolve),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return e;
+hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                      uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
+                      void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
+                      uint8_t *final_states) {
+    if (n_slices == 0) return hipSuccess;
+    uint8_t *w = static_cast<uint8_t *>(workspace);
+    uint8_t *res = w;                                        w += up256(pl->res_total + 32);
+    uint8_t *sorted = w;                                     w += up256(pl->res_total + 32);
+    uint32_t *pos = reinterpret_cast<uint32_t *>(w);         w += up256(4 * (pl->res_total + 32));
+    uint32_t *hist = reinterpret_cast<uint32_t *>(w);        w += up256(uint64_t(pl->total_blocks) * n_states * 4 + 16);
+    uint32_t *run_start = reinterpret_cast<uint32_t *>(w);   w += up256(n_slices * uint64_t(n_states + 1) * 4 + 16);
+    Seg *seg = reinterpret_cast<Seg *>(w);                   w += up256(uint64_t(pl->total_chunks) * sizeof(Seg));
+    uint8_t *entry = w;                                      w += up256(uint64_t(pl->total_chunks) + 16);
+    Stretch *st = reinterpret_cast<Stretch *>(w);            w += up256(uint64_t(pl->total_chunks) * sizeof(Stretch));
+    Entry *en = reinterpret_cast<Entry *>(w);                w += up256(uint64_t(pl->total_chunks) * sizeof(Entry));
+    SliceTotals *tot = reinterpret_cast<SliceTotals *>(w);   w += up256(n_slices * sizeof(SliceTotals));
+    uint32_t *S = reinterpret_cast<uint32_t *>(w);
+    const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
+                 pl->dig_off, n_states};
+    uint32_t key_bits = 0;
+    while ((1u << key_bits) < n_states) key_bits++;
+
+    const uint32_t slice_blocks = (n_slices + 63) / 64, chunk_blocks = (pl->total_chunks + 255) / 256;
+    if (n_states > 0) {
+        hipLaunchKernelGGL(k_k1p_hist, dim3(pl->total_blocks), dim3(256), 0, s, p, status, hist);
+        hipLaunchKernelGGL(k_k1p_scan, dim3(n_slices), dim3(1024), 0, s, p, hist, run_start);
+        hipLaunchKernelGGL(k_k1p_scatter, dim3(pl->total_blocks), dim3(64), 0, s, p, status, hist, sorted, pos, key_bits);
+        hipLaunchKernelGGL(k_k1p_spec, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
+                           sorted, seg);
+        hipLaunchKernelGGL(k_k1p_link, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
+                           sorted, seg, entry);
+        hipLaunchKernelGGL(k_k1p_chain, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
+                           sorted, seg, entry, final_states);
     }
-    const uint32_t slice_blocks = (n_slices + 63) / 64, chunk_blocks = (total_chunks + 255) / 256;
-    hipLaunchKernelGGL(k_k1p_resolve, dim3(slice_blocks), dim3(64), lds, s, static_cast<const uint4 *>(tiles), tile_off,
-                       n_bins, order, n_slices, init_states, n_states, res, res_off, status, final_states);
-    hipLaunchKernelGGL(k_k1p_b1, dim3(chunk_blocks), dim3(256), 0, s, p, total_chunks, res, status, st);
+    hipLaunchKernelGGL(k_k1p_gather, dim3(pl->total_chunks), dim3(256), 0, s, p, sorted, pos, res, status);
+    hipLaunchKernelGGL(k_k1p_b1, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, status, st);
     hipLaunchKernelGGL(k_k1p_b2, dim3(slice_blocks), dim3(64), 0, s, p, n_slices, status, st, en, tot);
     hipLaunchKernelGGL(k_k1p_zero, dim3(n_slices), dim3(256), 0, s, p, tot, S);
-    hipLaunchKernelGGL(k_k1p_c, dim3(chunk_blocks), dim3(256), 0, s, p, total_chunks, res, st, en, tot, S);
-    hipLaunchKernelGGL(k_k1p_d, dim3(slice_blocks), dim3(64), 0, s, p, n_slices, tot, S, out, out_off, out_len, status);
+    hipLaunchKernelGGL(k_k1p_c, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
+    hipLaunchKernelGGL(k_k1p_d, dim3(n_slices), dim3(256), 0, s, p, tot, S, out, out_off, out_len, status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // slices the scheme declined (status AVR_SLICE_RETRY_SERIAL) are coded by the serial kernel
-    return launch_cabac_encode(true, s, tiles, tile_off, n_bins, order, n_slices, init_states, n_states, out, out_off,
+    return launch_cabac_encode(false, s, recs, rec_off, n_bins, nullptr, n_slices, init_states, n_states, out, out_off,
                                out_len, status, nullptr, AVR_SLICE_RETRY_SERIAL);
 }
 

@@ -321,10 +321,11 @@ __global__ __launch_bounds__(64) void k_compact(const uint8_t *out, const uint64
 
 struct TileRecordSink {               // gathers 8 records, stores one 16-byte chunk
     uint4 *dst;                       // chunk 0 of this lane
+    uint32_t stride;                  // chunks between two of its chunks: 64 in a tile, 1 slice-major
     uint32_t n;
     uint32_t nop2;                    // two no-op records (padding)
     uint32_t w[4];
-    __device__ TileRecordSink(uint4 *d, uint32_t nop) : dst(d), n(0), nop2(nop | (nop << 16)) {
+    __device__ TileRecordSink(uint4 *d, uint32_t nop, uint32_t stride_ = 64) : dst(d), stride(stride_), n(0), nop2(nop | (nop << 16)) {
         w[0] = w[1] = w[2] = w[3] = nop2;
     }
     __device__ void put_record(uint16_t rec) {
@@ -332,14 +333,14 @@ struct TileRecordSink {               // gathers 8 records, stores one 16-byte c
         w[j >> 1] = (w[j >> 1] & ~(0xffffu << sh)) | (uint32_t(rec) << sh);
         n++;
         if ((n & 7) == 0) {
-            dst[size_t((n >> 3) - 1) * 64] = make_uint4(w[0], w[1], w[2], w[3]);
+            dst[size_t((n >> 3) - 1) * stride] = make_uint4(w[0], w[1], w[2], w[3]);
             w[0] = w[1] = w[2] = w[3] = nop2;
         }
     }
     __device__ void flush(uint32_t tile_chunks) {
         uint32_t c = n >> 3;
-        if (n & 7) { dst[size_t(c) * 64] = make_uint4(w[0], w[1], w[2], w[3]); c++; }
-        for (; c < tile_chunks; c++) dst[size_t(c) * 64] = make_uint4(nop2, nop2, nop2, nop2);
+        if (n & 7) { dst[size_t(c) * stride] = make_uint4(w[0], w[1], w[2], w[3]); c++; }
+        for (; c < tile_chunks; c++) dst[size_t(c) * stride] = make_uint4(nop2, nop2, nop2, nop2);
     }
 };
 
@@ -377,6 +378,26 @@ __global__ __launch_bounds__(64) void k_synth_tiles(
         }
     }
     rs.flush(tile_chunks);
+}
+
+__global__ __launch_bounds__(64) void k_synth_slices(
+    int workload, uint32_t scale, uint64_t seed, uint64_t first_slice, int kind,
+    uint32_t n_slices, const uint64_t *rec_off, uint16_t *recs, uint8_t *init_states, uint32_t n_states) {
+    const uint32_t slice = blockIdx.x * 64 + threadIdx.x;
+    if (slice >= n_slices) return;
+    const uint32_t chunks = uint32_t((rec_off[slice + 1] - rec_off[slice]) >> 3);
+    TileRecordSink rs(reinterpret_cast<uint4 *>(recs + rec_off[slice]), kind == AVR_KIND_CABAC ? AVR_NOP_CABAC : AVR_NOP_RANGE, 1);
+    if (kind == AVR_KIND_CABAC) {
+        CabacSink<TileRecordSink> sink(rs);
+        synth_slice(workload, scale, seed, first_slice + slice, sink);
+        if (init_states)
+            for (uint32_t c = 0; c < n_states; c++)
+                init_states[size_t(slice) * n_states + c] = synth_init_state(c, seed, first_slice + slice);
+    } else {
+        ModelSink<TileRecordSink> sink(rs);
+        synth_slice(workload, scale, seed, first_slice + slice, sink);
+    }
+    rs.flush(chunks);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -443,6 +464,15 @@ hipError_t launch_synth_count(hipStream_t s, int workload, uint32_t scale, uint6
     if (n_slices == 0) return hipSuccess;
     hipLaunchKernelGGL(k_synth_count, dim3((n_slices + 63) / 64), dim3(64), 0, s, workload, scale, seed,
                        first_slice, kind, n_slices, n_bins);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_slices(hipStream_t s, int workload, uint32_t scale, uint64_t seed, uint64_t first_slice,
+                               int kind, uint32_t n_slices, const uint64_t *rec_off, uint16_t *recs,
+                               uint8_t *init_states, uint32_t n_states) {
+    if (n_slices == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_synth_slices, dim3((n_slices + 63) / 64), dim3(64), 0, s, workload, scale, seed, first_slice,
+                       kind, n_slices, rec_off, recs, init_states, n_states);
     return hipGetLastError();
 }
 

@@ -140,37 +140,55 @@ class DeviceWorkload:
         encode_tiles(self.kind, self.tiles, self.tile_off, self.n_bins, self.order, self.out, self.out_off,
                      self.out_len, self.status, self.init_states, self.n_states, self.final_states, self.device_index)
 
+    def _slice_major(self):
+        """Slice-major records on the device (what the intra-slice parallel path reads)."""
+        import torch
+        if getattr(self, "rec_flat", None) is None:
+            dev = self.n_bins.device
+            nb = self.n_bins.to(torch.int64)
+            self.rec_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum((nb + 7) // 8 * 8, 0)])
+            self.rec_flat = torch.empty(int(self.rec_off[-1]) + 8, dtype=torch.int16, device=dev)
+            _check(lib().avr_synth_generate_slices_device(
+                self.device_index, _stream_ptr(torch), ctypes.byref(self.cfg), self.kind, self.n_slices,
+                self.rec_off.data_ptr(), self.rec_flat.data_ptr(), None))
+        return self.rec_flat, self.rec_off
+
     def _chunk_plan(self):
         """Plan arrays and workspace of the intra-slice parallel path (built once, reused)."""
         import torch
-        from . import CHUNK_BINS
+        from . import CHUNK_BINS, SORT_BLOCK_BINS, ChunkPlan
         if getattr(self, "_plan", None) is None:
             dev = self.n_bins.device
             nb = self.n_bins.to(torch.int64)
             zero = torch.zeros(1, dtype=torch.int64, device=dev)
+            ar = torch.arange(self.n_slices, device=dev)
             res_off = torch.cat([zero, torch.cumsum((nb + 15) // 16 * 16 + 16, 0)])
             n_chunks = torch.clamp((nb + CHUNK_BINS - 1) // CHUNK_BINS, min=1)
-            chunk_base = torch.cat([zero, torch.cumsum(n_chunks, 0)])
+            n_blocks = torch.clamp((nb + SORT_BLOCK_BINS - 1) // SORT_BLOCK_BINS, min=1)
+            chunk_base = torch.cat([zero, torch.cumsum(n_chunks, 0)]).to(torch.int32)
+            blk_base = torch.cat([zero, torch.cumsum(n_blocks, 0)]).to(torch.int32)
             dig_off = torch.cat([zero, torch.cumsum(nb // 2 + 8, 0)])
-            chunk_slice = torch.repeat_interleave(torch.arange(self.n_slices, device=dev), n_chunks).to(torch.int32)
-            res_total, total_chunks, dig_total = int(res_off[-1]), int(chunk_base[-1]), int(dig_off[-1])
-            ws_bytes = lib().avr_cabac_chunked_workspace_bytes(self.n_slices, res_total, total_chunks, dig_total)
-            self._plan = dict(res_off=res_off, chunk_base=chunk_base.to(torch.int32), chunk_slice=chunk_slice,
-                              dig_off=dig_off, res_total=res_total, total_chunks=total_chunks, dig_total=dig_total,
-                              ws=torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev), ws_bytes=ws_bytes)
+            t = dict(res_off=res_off, chunk_base=chunk_base, blk_base=blk_base, dig_off=dig_off,
+                     chunk_slice=torch.repeat_interleave(ar, n_chunks).to(torch.int32),
+                     blk_slice=torch.repeat_interleave(ar, n_blocks).to(torch.int32))
+            plan = ChunkPlan(t["res_off"].data_ptr(), t["chunk_base"].data_ptr(), t["chunk_slice"].data_ptr(),
+                             t["blk_base"].data_ptr(), t["blk_slice"].data_ptr(), t["dig_off"].data_ptr(),
+                             int(res_off[-1]), int(dig_off[-1]), int(chunk_base[-1]), int(blk_base[-1]))
+            ws_bytes = lib().avr_cabac_chunked_workspace_bytes(self.n_slices, self.n_states, ctypes.byref(plan))
+            self._plan = dict(tensors=t, plan=plan, ws_bytes=ws_bytes,
+                              ws=torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev))
         return self._plan
 
     def encode_chunked(self):
         """K1 through the intra-slice parallel kernels (same bytes as encode())."""
         import torch
         assert self.kind == KIND_CABAC
+        recs, rec_off = self._slice_major()
         p = self._chunk_plan()
         ws_ptr = (p["ws"].data_ptr() + 255) // 256 * 256
         _check(lib().avr_cabac_encode_chunked_device(
-            self.device_index, _stream_ptr(torch), self.tiles.data_ptr(), self.tile_off.data_ptr(), self.n_bins.data_ptr(),
-            self.order.data_ptr(), self.n_slices, self.init_states.data_ptr(), self.n_states,
-            p["res_off"].data_ptr(), p["res_total"], p["chunk_base"].data_ptr(), p["chunk_slice"].data_ptr(),
-            p["total_chunks"], p["dig_off"].data_ptr(), p["dig_total"], ws_ptr, p["ws_bytes"],
+            self.device_index, _stream_ptr(torch), recs.data_ptr(), rec_off.data_ptr(), self.n_bins.data_ptr(),
+            self.n_slices, self.init_states.data_ptr(), self.n_states, ctypes.byref(p["plan"]), ws_ptr, p["ws_bytes"],
             self.out.data_ptr(), self.out_off.data_ptr(), self.out_len.data_ptr(), self.status.data_ptr(),
             self.final_states.data_ptr() if self.final_states is not None else None))
 

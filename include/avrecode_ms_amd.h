@@ -162,29 +162,42 @@ int avr_range_encode_tiles_device(int device, void *stream,
 
 /* K1, intra-slice parallel form ("K1p", avrecode-ms_amd/csrc/avr_k1p.h): the same bytes as
  * avr_cabac_encode_tiles_device, produced by many lanes per slice -- for batches of few, long
- * slices (a 1-slice-per-frame clip), where one lane per slice leaves the chip idle.  A slice is
- * cut into chunks of AVR_CHUNK_BINS bins; the caller supplies the plan (device arrays):
- *   res_off[i]     byte offset of slice i's resolved codes in the workspace, multiple of 16,
- *                  res_off[i+1] - res_off[i] >= roundup16(n_bins[i]) + 16;  res_total = res_off[n]
- *   chunk_base[i]  first global chunk of slice i; slice i has max(1, ceil(n_bins[i]/AVR_CHUNK_BINS))
- *                  chunks; total_chunks = chunk_base[n];  chunk_slice[c] = slice of global chunk c
+ * slices (a 1-slice-per-frame clip), where one lane per slice leaves the chip idle.  Input is the
+ * slice-major layout (padding records must be no-ops).  Context states are resolved by a stable
+ * per-slice counting sort over blocks of AVR_SORT_BLOCK_BINS bins; the arithmetic coding runs per
+ * chunk of AVR_CHUNK_BINS bins.  The caller supplies the plan (device arrays, n = n_slices):
+ *   res_off[i]     byte offset of slice i in the per-bin work arrays, multiple of 16,
+ *                  res_off[i+1] - res_off[i] >= roundup16(n_bins[i]) + 16;      res_total = res_off[n]
+ *   chunk_base[i]  first global chunk of slice i; it has max(1, ceil(n_bins[i]/AVR_CHUNK_BINS))
+ *                  chunks; total_chunks = chunk_base[n]; chunk_slice[c] = slice of global chunk c
+ *   blk_base[i], blk_slice[b], total_blocks: the same for blocks of AVR_SORT_BLOCK_BINS bins
  *   dig_off[i]     first 32-bit digit sum of slice i, dig_off[i+1] - dig_off[i] >= n_bins[i]/2 + 8;
  *                  dig_total = dig_off[n]
  * workspace: avr_cabac_chunked_workspace_bytes(...) bytes of device memory, 256-byte aligned.
- * Arguments shared with avr_cabac_encode_tiles_device mean the same (status is in/out).  A slice
- * the scheme declines (no coded LPS for 16 consecutive chunks) is coded by the serial kernel in
- * the same call. */
-#define AVR_CHUNK_BINS 1024
-size_t avr_cabac_chunked_workspace_bytes(size_t n_slices, uint64_t res_total, uint32_t total_chunks,
-                                         uint64_t dig_total);
+ * status is in/out as for the tile kernels; this path validates every record itself.  A slice the
+ * scheme declines (no coded LPS for 16 consecutive chunks) is coded by the serial kernel in the
+ * same call. */
+#define AVR_CHUNK_BINS       1024
+#define AVR_SORT_BLOCK_BINS  16384
+typedef struct {
+    const uint64_t *res_off;
+    const uint32_t *chunk_base;
+    const uint32_t *chunk_slice;
+    const uint32_t *blk_base;
+    const uint32_t *blk_slice;
+    const uint64_t *dig_off;
+    uint64_t res_total;
+    uint64_t dig_total;
+    uint32_t total_chunks;
+    uint32_t total_blocks;
+} avr_chunk_plan;
+
+size_t avr_cabac_chunked_workspace_bytes(size_t n_slices, size_t n_states, const avr_chunk_plan *plan);
 int avr_cabac_encode_chunked_device(int device, void *stream,
-                                    const void *tiles, const uint64_t *tile_off,
-                                    const uint32_t *n_bins, const uint32_t *order, size_t n_slices,
+                                    const uint16_t *recs, const uint64_t *rec_off,
+                                    const uint32_t *n_bins, size_t n_slices,
                                     const uint8_t *init_states, size_t n_states,
-                                    const uint64_t *res_off, uint64_t res_total,
-                                    const uint32_t *chunk_base, const uint32_t *chunk_slice,
-                                    uint32_t total_chunks, const uint64_t *dig_off, uint64_t dig_total,
-                                    void *workspace, size_t workspace_bytes,
+                                    const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes,
                                     uint8_t *out, const uint64_t *out_off,
                                     uint32_t *out_len, int32_t *status, uint8_t *final_states);
 
@@ -227,6 +240,10 @@ int avr_synth_generate_host(const avr_synth_config *cfg, int kind, size_t n_slic
                             const uint64_t *rec_off, uint16_t *recs, uint8_t *init_states);
 int avr_synth_count_device(int device, void *stream, const avr_synth_config *cfg, int kind,
                            size_t n_slices, uint32_t *n_bins);
+/* slice-major: slice i at recs + rec_off[i], rec_off multiples of 8, chunk padding = no-op records */
+int avr_synth_generate_slices_device(int device, void *stream, const avr_synth_config *cfg, int kind,
+                                     size_t n_slices, const uint64_t *rec_off, uint16_t *recs,
+                                     uint8_t *init_states);
 /* writes straight into the tile layout */
 int avr_synth_generate_tiles_device(int device, void *stream, const avr_synth_config *cfg, int kind,
                                     size_t n_slices, const uint32_t *order,

@@ -35,6 +35,15 @@ def test_chunked_random_and_declined_slices(avr, oracle):
     for i in range(40):
         n = int(rng.integers(0, 30000))
         slices.append(oracle_lib.random_cabac_stream(rng, n, 64, terminate=bool(i % 4)))
+    # shapes where the two extreme state chains of phase A never meet inside a segment (replay path)
+    n = 9000
+
+    def mk(bins, sels):
+        return (np.asarray(bins, np.uint16) | (np.asarray(sels, np.uint16) << 1)).astype(np.uint16)
+    slices.append((mk(np.arange(n) & 1, np.zeros(n)), np.zeros(64, np.uint8)))                 # alternating, one context
+    slices.append((mk(rng.integers(0, 2, n), np.zeros(n)), np.full(64, 60, np.uint8)))          # coin flips, one context
+    slices.append((mk(rng.integers(0, 2, 3 * n), rng.integers(0, 2, 3 * n)), np.full(64, 127, np.uint8)))   # pStateIdx 63
+    slices.append((mk((np.arange(4 * n) % 3 == 0), np.arange(4 * n) % 2), np.array([124, 125] * 32, np.uint8)))
     # slices the scheme declines (no coded LPS for > 16 chunks): must come back right via the serial kernel
     slices.append(((np.ones(40000, np.uint16) | (1024 << 1)).astype(np.uint16), np.zeros(64, np.uint8)))
     slices.append((np.ones(60000, np.uint16), np.full(64, 125, np.uint8)))

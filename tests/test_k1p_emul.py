@@ -119,3 +119,24 @@ def test_synthetic_slices(emul, oracle, avr):
             want = oracle.cabac_encode(r, s)
             data, final, info = k1p(emul, r, s)
             assert info[3] == 0 and (data, final) == want[:2], f"workload {w} slice {i}"
+
+
+def test_state_transitions_are_monotone(avr):
+    """What phase A's speculation rests on: in the order (62,MPS 0) < ... < (0,0) < (0,1) < ... < (62,1)
+    both CABAC transition functions (cabac_code.h:43-47) are non-decreasing, so two state chains that
+    have met stay together and bracket every chain started between them."""
+    _, mlps = avr.cabac_tables()
+
+    def sigma(s):
+        return (s >> 1) if s & 1 else -1 - (s >> 1)
+
+    def step(s, b):
+        return mlps[128 + s] if b == (s & 1) else mlps[127 - s]
+    states = sorted(range(126), key=sigma)                       # pStateIdx <= 62
+    assert sigma(124) == min(map(sigma, states)) and sigma(125) == max(map(sigma, states))
+    for b in (0, 1):
+        images = [sigma(step(s, b)) for s in states]
+        assert images == sorted(images), b
+        assert all(step(s, b) < 126 for s in states)             # pStateIdx 63 is never entered
+    for s in (126, 127):                                         # ... and never left
+        assert step(s, 0) == s and step(s, 1) == s
