@@ -31,7 +31,7 @@ KIND_CABAC, KIND_RANGE = 0, 1
 SEL_BYPASS, SEL_TERMINATE = 1024, 1025
 SLICE_OK, SLICE_ZERO_PROB, SLICE_OVERFLOW, SLICE_BAD_RECORD = 0, 1, 2, 3
 NOP_CABAC, NOP_RANGE = 1026 << 1, 0
-CHUNK_BINS, SORT_BLOCK_BINS = 1024, 16384
+CHUNK_BINS, SORT_BLOCK_BINS = 1024, 4096
 
 _SOURCES = ["avr_kernels.hip", "avr_k1p.hip", "avr_api.cpp"]
 _DEPS = _SOURCES + ["avr_coder.h", "avr_internal.h", "avr_k1p.h", "avr_synth.h", "avr_tables.h"]

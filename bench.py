@@ -168,7 +168,7 @@ def main():
 
     path = args.path
     if path == "auto":        # one lane per slice needs >= ~64 slices per SIMD-wave-slot to fill 256 CUs
-        path = "chunked" if (kind == avr.KIND_CABAC and n_slices < 65536 and w.total_bins // max(n_slices, 1) >= 8192) else "serial"
+        path = "chunked" if (kind == avr.KIND_CABAC and n_slices <= 32768 and w.total_bins // max(n_slices, 1) >= 8192) else "serial"
     if kind != avr.KIND_CABAC:
         path = "serial"
     step = w.encode_chunked if path == "chunked" else w.encode
@@ -219,7 +219,8 @@ def main():
                        "n_states": w.n_states, "layout": "wave-interleaved tiles", "path": path, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("k_k1p_* (resolve, b1, b2, zero, c, d)" if path == "chunked" else "k_cabac_encode<tiled>")
+                         "kernel": ("K1p: k_k1p_{hist,scan,scatter,spec,link,chain,gather,b1,b2,zero,c,d} (one step = 13 launches; "
+                                    "largest: k_k1p_scatter)" if path == "chunked" else "k_cabac_encode<tiled>")
                          if kind == avr.KIND_CABAC else "k_range_encode<tiled>",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
                          "bins_per_s": w.total_bins / (kernel_ms * 1e-3)},

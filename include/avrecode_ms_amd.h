@@ -178,7 +178,7 @@ int avr_range_encode_tiles_device(int device, void *stream,
  * scheme declines (no coded LPS for 16 consecutive chunks) is coded by the serial kernel in the
  * same call. */
 #define AVR_CHUNK_BINS       1024
-#define AVR_SORT_BLOCK_BINS  16384
+#define AVR_SORT_BLOCK_BINS  4096
 typedef struct {
     const uint64_t *res_off;
     const uint32_t *chunk_base;
