@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -128,6 +129,12 @@ struct avr_batch {
     DevBuf<uint32_t> d_n_bins, d_order, d_out_len;
     DevBuf<int32_t> d_status;
     DevBuf<uint8_t> d_states, d_final, d_out, d_dense;
+
+    // intra-slice parallel path (K1p): plan arrays + workspace
+    DevBuf<uint64_t> d_res_off, d_dig_off;
+    DevBuf<uint32_t> d_chunk_base, d_chunk_slice, d_blk_base, d_blk_slice;
+    DevBuf<uint8_t> d_workspace;
+    int last_path = 0;                      // 0 = one lane per slice, 1 = chunked
 };
 
 extern "C" {
@@ -178,6 +185,8 @@ void avr_batch_destroy(avr_batch *b) {
     b->d_out_off.release(); b->d_dense_off.release(); b->d_n_bins.release(); b->d_order.release();
     b->d_out_len.release(); b->d_status.release(); b->d_states.release(); b->d_final.release();
     b->d_out.release(); b->d_dense.release();
+    b->d_res_off.release(); b->d_dig_off.release(); b->d_chunk_base.release(); b->d_chunk_slice.release();
+    b->d_blk_base.release(); b->d_blk_slice.release(); b->d_workspace.release();
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -275,6 +284,45 @@ int avr_batch_run(avr_batch *b) {
     // the vectors above are pageable: the copies have been staged by the runtime when the calls return
     AVR_HIP(hipEventRecord(b->ev[1], s));
     AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
+    // One lane per slice needs tens of thousands of slices to fill the chip; a batch of few, long
+    // slices (a clip with one slice per frame) goes through the intra-slice parallel kernels.
+    bool chunked = cabac && n <= 32768 && b->total_bins / n >= 8192;
+    if (const char *force = getenv("AVR_K1_PATH")) chunked = cabac && strcmp(force, "chunked") == 0;
+    b->last_path = chunked;
+    if (chunked) {
+        std::vector<uint64_t> res_off(n + 1, 0), dig_off(n + 1, 0);
+        std::vector<uint32_t> chunk_base(n + 1, 0), blk_base(n + 1, 0), chunk_slice, blk_slice;
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t nb = b->n_bins[i];
+            res_off[i + 1] = res_off[i] + ((nb + 15) & ~uint64_t(15)) + 16;
+            dig_off[i + 1] = dig_off[i] + nb / 2 + 8;
+            const uint32_t nc = uint32_t(std::max<uint64_t>(1, (nb + AVR_CHUNK_BINS - 1) / AVR_CHUNK_BINS));
+            const uint32_t nk = uint32_t(std::max<uint64_t>(1, (nb + AVR_SORT_BLOCK_BINS - 1) / AVR_SORT_BLOCK_BINS));
+            chunk_base[i + 1] = chunk_base[i] + nc;
+            blk_base[i + 1] = blk_base[i] + nk;
+            chunk_slice.insert(chunk_slice.end(), nc, uint32_t(i));
+            blk_slice.insert(blk_slice.end(), nk, uint32_t(i));
+        }
+        if ((rc = b->d_res_off.reserve(n + 1)) || (rc = b->d_dig_off.reserve(n + 1)) || (rc = b->d_chunk_base.reserve(n + 1)) ||
+            (rc = b->d_blk_base.reserve(n + 1)) || (rc = b->d_chunk_slice.reserve(chunk_slice.size())) ||
+            (rc = b->d_blk_slice.reserve(blk_slice.size())))
+            return rc;
+        avr_chunk_plan plan{b->d_res_off.p, b->d_chunk_base.p, b->d_chunk_slice.p, b->d_blk_base.p, b->d_blk_slice.p, b->d_dig_off.p,
+                            res_off.back(), dig_off.back(), chunk_base.back(), blk_base.back()};
+        const size_t ws = avr::k1p_workspace_bytes(n, uint32_t(ns), &plan);
+        if ((rc = b->d_workspace.reserve(ws + 256))) return rc;
+        AVR_HIP(hipMemcpyAsync(b->d_res_off.p, res_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+        AVR_HIP(hipMemcpyAsync(b->d_dig_off.p, dig_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+        AVR_HIP(hipMemcpyAsync(b->d_chunk_base.p, chunk_base.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
+        AVR_HIP(hipMemcpyAsync(b->d_blk_base.p, blk_base.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
+        AVR_HIP(hipMemcpyAsync(b->d_chunk_slice.p, chunk_slice.data(), chunk_slice.size() * 4, hipMemcpyHostToDevice, s));
+        AVR_HIP(hipMemcpyAsync(b->d_blk_slice.p, blk_slice.data(), blk_slice.size() * 4, hipMemcpyHostToDevice, s));
+        AVR_HIP(hipStreamSynchronize(s));                        // the plan vectors are pageable locals
+        AVR_HIP(hipEventRecord(b->ev[2], s));
+        uint8_t *wsp = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(b->d_workspace.p) + 255) & ~uintptr_t(255));
+        AVR_HIP(avr::launch_k1p(s, b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, n32, b->d_states.p, uint32_t(ns), &plan, wsp,
+                                b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p, b->d_final.p));
+    } else {
     AVR_HIP(avr::launch_pack_tiles(s, b->kind, uint32_t(ns), b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, b->d_order.p, n32,
                                    b->d_tile_off.p, b->d_tiles.p, b->d_status.p));
     AVR_HIP(hipEventRecord(b->ev[2], s));
@@ -284,6 +332,7 @@ int avr_batch_run(avr_batch *b) {
     else
         AVR_HIP(avr::launch_range_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_out.p,
                                          b->d_out_off.p, b->d_out_len.p, b->d_status.p));
+    }
     AVR_HIP(hipEventRecord(b->ev[3], s));
     AVR_HIP(hipMemcpyAsync(b->h_out_len.p, b->d_out_len.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     AVR_HIP(hipMemcpyAsync(b->h_status.p, b->d_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -1,0 +1,384 @@
+// compressor / decompressor / roundtrip: the orchestration of the reference (recode.cpp:1109-1640)
+// around the GPU batches.  Block bookkeeping, literal gaps, skip blocks, surrogate payloads and
+// the tail patch follow the reference line by line in behaviour; what differs is WHEN bins are
+// coded: the recorders collect them per slice and one avr_batch codes all slices of the file at
+// the end of run() (legal because nothing reads the coded bytes earlier: recode.cpp:1131,
+// 1352-1363).
+//
+// libavcodec's place is taken by anything that drives `hooks` (the callback table the reference
+// installs with codec->hooks = &hooks, recode.cpp:130, 219-235).  The reference's fork of FFmpeg
+// is not available offline; tests drive the same table from recorded slices (slice_feeder).
+#pragma once
+#include <algorithm>
+#include <memory>
+
+#include "avr_host.h"
+
+namespace avr {
+namespace host {
+
+// The callback surface of recode.cpp:149-216, with the same names, order and arity.  `ctx` stands
+// for libavcodec's CABACContext*: the hook adapter only uses it as the identity of the decoder
+// (recode.cpp:153, 236).  A null return from init_decoder means "hooks disabled for this slice"
+// (the reference nulls ctx->coding_hooks and calls ff_reset_cabac_decoder, :1148-1150, 1433-1435).
+struct hooks {
+    void *opaque;
+    struct {
+        void *(*init_decoder)(void *opaque, void *ctx, const uint8_t *buf, int size);
+        int (*get)(void *opaque, uint8_t *state);
+        int (*get_bypass)(void *opaque);
+        int (*get_terminate)(void *opaque);
+        const uint8_t *(*skip_bytes)(void *opaque, int n);
+    } cabac;
+    struct {
+        void (*frame_spec)(void *opaque, int frame_num, int mb_width, int mb_height);
+        void (*mb_xy)(void *opaque, int x, int y);
+        void (*begin_sub_mb)(void *opaque, int cat, int scan8index, int max_coeff, int is_dc, int chroma422);
+        void (*end_sub_mb)(void *opaque, int cat, int scan8index, int max_coeff, int is_dc, int chroma422);
+        void (*begin_coding_type)(void *opaque, int ct, int zigzag_index, int param0, int param1);
+        void (*end_coding_type)(void *opaque, int ct);
+    } model;
+};
+
+// What decodes the stream and calls the hooks: libavcodec in the reference (av_decoder,
+// recode.cpp:80-237).  read_packet is the custom AVIO callback (recode.cpp:145-148).
+struct stream_decoder {
+    virtual ~stream_decoder() {}
+    // decode everything, pulling bytes through read_packet(opaque, buffer, size) and calling h
+    virtual void decode_video(hooks *h, int (*read_packet)(void *, uint8_t *, int), void *opaque) = 0;
+};
+
+inline void gpu_check(int rc) { if (rc < 0) throw std::runtime_error(std::string("avr: ") + avr_last_error()); }
+
+struct batch_holder {                                    // RAII around the C ABI's avr_batch
+    avr_batch *b;
+    batch_holder(int device, size_t max_slices, size_t max_bins) : b(avr_batch_create(device, max_slices, max_bins)) {
+        if (!b) throw std::runtime_error(std::string("avr: ") + avr_last_error());
+    }
+    ~batch_holder() { avr_batch_destroy(b); }
+};
+
+template <class Driver>
+struct hook_adapter {                                    // av_decoder<Driver>'s stubs, recode.cpp:149-216
+    static hooks make(Driver *d) {
+        hooks h{};
+        h.opaque = d;
+        h.cabac.init_decoder = [](void *o, void *ctx, const uint8_t *buf, int size) -> void * {
+            Driver *self = static_cast<Driver *>(o);
+            auto dec = std::unique_ptr<typename Driver::cabac_decoder>(new typename Driver::cabac_decoder(self, buf, size));
+            typename Driver::cabac_decoder *raw = dec->hooked() ? dec.get() : nullptr;
+            self->cabac_contexts[ctx] = std::move(dec);  // re-init of the same context replaces it (:153)
+            return raw;
+        };
+        h.cabac.get = [](void *o, uint8_t *state) { return static_cast<typename Driver::cabac_decoder *>(o)->get(state); };
+        h.cabac.get_bypass = [](void *o) { return static_cast<typename Driver::cabac_decoder *>(o)->get_bypass(); };
+        h.cabac.get_terminate = [](void *o) { return static_cast<typename Driver::cabac_decoder *>(o)->get_terminate(); };
+        h.cabac.skip_bytes = [](void *, int) -> const uint8_t * {
+            throw std::runtime_error("Not implemented: CABAC decoder doesn't use skip_bytes.");     // :168-170
+        };
+        h.model.frame_spec = [](void *, int, int, int) {};           // frame store: out of scope
+        h.model.mb_xy = [](void *, int, int) {};
+        h.model.begin_sub_mb = [](void *, int, int, int, int, int) {};
+        h.model.end_sub_mb = [](void *, int, int, int, int, int) {};
+        h.model.begin_coding_type = [](void *, int, int, int, int) {};   // "Not called" (recode.cpp:204, 210)
+        h.model.end_coding_type = [](void *, int) {};
+        return h;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+class compressor {                                       // recode.cpp:1109-1316
+  public:
+    compressor(const std::string &original_bytes, int device = 0) : original_(original_bytes), device_(device) {}
+
+    std::string run(stream_decoder *d) {                 // :1122-1132
+        hooks h = hook_adapter<compressor>::make(this);
+        d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<compressor *>(o)->read_packet(buf, size); }, this);
+        cabac_contexts.clear();
+        code_pending();
+        Block final_literal;
+        final_literal.has_literal = true;
+        final_literal.literal = original_.substr(prev_coded_block_end_);
+        out_.block.push_back(final_literal);
+        return out_.SerializeAsString();
+    }
+
+    int read_packet(uint8_t *buffer_out, int size) {     // :1134-1139
+        size = std::min<int>(size, int(original_.size() - read_offset_));
+        memcpy(buffer_out, original_.data() + read_offset_, size);
+        read_offset_ += size;
+        return size;
+    }
+
+    class cabac_decoder {                                // :1141-1275
+      public:
+        cabac_decoder(compressor *c, const uint8_t *buf, int size) : c_(c), decoder_(buf, size) {
+            block_ = c->find_next_coded_block_and_emit_literal(buf, size);
+            if (block_ < 0) return;                      // skipped: hooks off for this slice (:1146-1152)
+            c->out_.block[block_].has_size = true;       // :1154
+            c->out_.block[block_].size = size;
+            if (!c->state_base_) throw std::runtime_error("compressor: the decoder did not register its state array");
+            recorder_.reset(new compress_recorder(&c->model_));   // :1161-1163
+            base_ = c->state_base_;
+        }
+        ~cabac_decoder() { if (recorder_) c_->pending_.push_back({block_, recorder_->records()}); }
+        bool hooked() const { return block_ >= 0; }
+        int get(uint8_t *state) {                        // :1182-1186
+            const int symbol = decoder_.get(state);      // ::ff_get_cabac on the private context copy
+            const ptrdiff_t context = state - base_;     // context identity is the address (recode.cpp:325)
+            if (context < 0 || context >= AVR_MAX_STATES) throw std::invalid_argument("compressor: state pointer outside cabac_state[]");
+            recorder_->execute_symbol(symbol, int(context));
+            return symbol;
+        }
+        int get_bypass() {                               // :1188-1192
+            const int symbol = decoder_.get_bypass();
+            recorder_->execute_symbol(symbol, kKeyBypass);
+            return symbol;
+        }
+        int get_terminate() {                            // :1194-1199
+            const int symbol = decoder_.get_terminate() != 0;
+            recorder_->execute_symbol(symbol, kKeyTerminate);
+            return symbol;
+        }
+
+      private:
+        compressor *c_;
+        cabac_bin_decoder decoder_;
+        int block_ = -1;
+        std::unique_ptr<compress_recorder> recorder_;
+        const uint8_t *base_ = nullptr;
+    };
+
+    // the decoder's cabac_state[] for the slices to come (stands for the address arithmetic on
+    // libavcodec's H264SliceContext that a real integration does)
+    void set_state_base(const uint8_t *base) { state_base_ = base; }
+    std::map<void *, std::unique_ptr<cabac_decoder>> cabac_contexts;     // :236
+
+  private:
+    // :1282-1304; returns the index of the block the recoder fills, or -1 for a skipped slice
+    int find_next_coded_block_and_emit_literal(const uint8_t *buf, int size) {
+        const char *hay = original_.data() + prev_coded_block_end_;
+        const size_t hay_len = read_offset_ - prev_coded_block_end_;
+        const char *found = size > 0 ? static_cast<const char *>(memmem(hay, hay_len, buf, size)) : nullptr;
+        if (found && size >= SURROGATE_MARKER_BYTES) {
+            const size_t gap = found - hay;
+            Block lit;
+            lit.has_literal = true;
+            lit.literal.assign(hay, gap);
+            out_.block.push_back(lit);
+            prev_coded_block_end_ += gap + size;
+            Block nb;
+            nb.has_length_parity = true;
+            nb.length_parity = size & 1;
+            if (size > 1) { nb.has_last_byte = true; nb.last_byte.assign(reinterpret_cast<const char *>(buf) + size - 1, 1); }
+            out_.block.push_back(nb);
+            return int(out_.block.size()) - 1;
+        }
+        Block skip;                                      // probably NAL-escaped: leave it in the literal stream
+        skip.has_skip_coded = true; skip.skip_coded = true;
+        skip.has_size = true; skip.size = size;
+        out_.block.push_back(skip);
+        return -1;
+    }
+
+    void code_pending() {                                // one K2 batch for the whole file
+        if (pending_.empty()) return;
+        size_t bins = 0;
+        for (auto &p : pending_) bins += p.recs.size();
+        batch_holder bh(device_, pending_.size(), bins + 8);
+        for (auto &p : pending_) gpu_check(avr_batch_add_slice_range(bh.b, p.recs.data(), p.recs.size()));
+        gpu_check(avr_batch_run(bh.b));
+        for (size_t i = 0; i < pending_.size(); i++) {
+            const uint8_t *bytes; size_t len; int status;
+            gpu_check(avr_batch_get(bh.b, i, &bytes, &len, &status));
+            if (status == AVR_SLICE_ZERO_PROB) throw std::runtime_error("Encoder error: emitted a zero-probability symbol.");   // arithmetic_code.h:117
+            if (status != AVR_SLICE_OK) throw std::runtime_error("avr: slice status " + std::to_string(status));
+            Block &b = out_.block[pending_[i].block];
+            b.has_cabac = true;                          // out->set_cabac, recode.cpp:1101
+            b.cabac.assign(reinterpret_cast<const char *>(bytes), len);
+        }
+        pending_.clear();
+    }
+
+    struct pending { int block; std::vector<uint16_t> recs; };
+    std::string original_;
+    int device_;
+    int read_offset_ = 0, prev_coded_block_end_ = 0;
+    const uint8_t *state_base_ = nullptr;
+    h264_model model_;
+    Recoded out_;
+    std::vector<pending> pending_;
+};
+
+// ---------------------------------------------------------------------------------------------
+class decompressor {                                     // recode.cpp:1319-1598
+    struct block_state {                                 // :1321-1328
+        bool coded = false;
+        std::string surrogate_marker, out_bytes;
+        bool done = false;
+        int8_t length_parity = -1;
+        uint8_t last_byte = 0;
+    };
+
+  public:
+    decompressor(const std::string &in_bytes, int device = 0) : device_(device) {
+        if (!in_.ParseFromArray(in_bytes.data(), in_bytes.size())) throw std::invalid_argument("Failed to parse the recoded input");
+    }
+
+    std::string run(stream_decoder *d) {                 // :1345-1364
+        blocks_.clear();
+        blocks_.resize(in_.block.size());
+        hooks h = hook_adapter<decompressor>::make(this);
+        d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<decompressor *>(o)->read_packet(buf, size); }, this);
+        cabac_contexts.clear();
+        code_pending();
+        std::string out;
+        for (auto &block : blocks_) {
+            if (!block.done) throw std::runtime_error("Not all blocks were decoded.");
+            if (block.length_parity != -1) {             // :1354-1361, through the C ABI's helper
+                block.out_bytes.push_back('\0');
+                const size_t n = avr_tail_patch(reinterpret_cast<uint8_t *>(&block.out_bytes[0]), block.out_bytes.size() - 1,
+                                                block.length_parity, block.last_byte);
+                block.out_bytes.resize(n);
+            }
+            out += block.out_bytes;
+        }
+        return out;
+    }
+
+    int read_packet(uint8_t *buffer_out, int size) {     // :1366-1416
+        uint8_t *p = buffer_out;
+        while (size > 0 && read_index_ < int(in_.block.size())) {
+            if (read_block_.empty()) {
+                const Block &block = in_.block[read_index_];
+                if (int(block.has_literal) + int(block.has_cabac) + int(block.has_skip_coded) != 1)
+                    throw std::runtime_error("Invalid input block: must have exactly one type");
+                if (block.has_literal) {
+                    blocks_[read_index_].out_bytes = block.literal;
+                    blocks_[read_index_].done = true;
+                    read_block_ = block.literal;
+                } else if (block.has_cabac) {
+                    blocks_[read_index_].coded = true;
+                    blocks_[read_index_].surrogate_marker = next_surrogate_marker(&surrogate_marker_sequence_number_);
+                    blocks_[read_index_].done = false;
+                    if (!block.has_size) throw std::runtime_error("CABAC block requires size field.");
+                    if (block.has_length_parity && block.has_last_byte && !block.last_byte.empty()) {
+                        blocks_[read_index_].length_parity = block.length_parity;
+                        blocks_[read_index_].last_byte = uint8_t(block.last_byte[0]);
+                    }
+                    read_block_ = make_surrogate_block(blocks_[read_index_].surrogate_marker, size_t(block.size));
+                } else if (block.has_skip_coded && block.skip_coded) {
+                    blocks_[read_index_].coded = true;
+                    blocks_[read_index_].done = true;
+                } else {
+                    throw std::runtime_error("Unknown input block type");
+                }
+            }
+            if (size_t(read_offset_) < read_block_.size()) {
+                const int n = int(read_block_.copy(reinterpret_cast<char *>(p), size, read_offset_));
+                read_offset_ += n; p += n; size -= n;
+            }
+            if (size_t(read_offset_) >= read_block_.size()) { read_block_.clear(); read_offset_ = 0; read_index_++; }
+        }
+        return int(p - buffer_out);
+    }
+
+    class cabac_decoder {                                // :1418-1527
+      public:
+        cabac_decoder(decompressor *d, const uint8_t *buf, int size) : d_(d) {
+            index_ = d->recognize_coded_block(buf, size);
+            const Block &block = d->in_.block[index_];
+            if (block.has_cabac) {
+                if (!d->state_base_) throw std::runtime_error("decompressor: the decoder did not register its state array");
+                recorder_.reset(new decompress_recorder(&d->model_, reinterpret_cast<const uint8_t *>(block.cabac.data()),
+                                                        block.cabac.size(), d->state_base_));
+            } else if (!(block.has_skip_coded && block.skip_coded)) {
+                throw std::runtime_error("Expected CABAC block.");
+            }
+        }
+        ~cabac_decoder() {
+            if (recorder_) d_->pending_.push_back({index_, recorder_->records(),
+                                                   std::vector<uint8_t>(recorder_->init_states(), recorder_->init_states() + AVR_MAX_STATES)});
+        }
+        bool hooked() const { return bool(recorder_); }
+        int get(uint8_t *state) { return recorder_->get(state); }
+        int get_bypass() { return recorder_->get_bypass(); }
+        int get_terminate() { return recorder_->get_terminate(); }
+
+      private:
+        decompressor *d_;
+        int index_;
+        std::unique_ptr<decompress_recorder> recorder_;
+    };
+
+    void set_state_base(const uint8_t *base) { state_base_ = base; }
+    std::map<void *, std::unique_ptr<cabac_decoder>> cabac_contexts;
+
+  private:
+    int recognize_coded_block(const uint8_t *buf, int size) {      // :1553-1580
+        while (!blocks_[next_coded_block_].coded) {
+            if (next_coded_block_ >= read_index_) throw std::runtime_error("Coded block expected, but not recorded in the compressed data.");
+            next_coded_block_++;
+        }
+        const int index = next_coded_block_++;
+        const Block &block = in_.block[index];
+        if (block.has_cabac) {
+            if (block.size != size) throw std::runtime_error("Invalid surrogate block size.");
+            const std::string header(reinterpret_cast<const char *>(buf), blocks_[index].surrogate_marker.size());
+            if (blocks_[index].surrogate_marker != header) throw std::runtime_error("Invalid surrogate marker in coded block.");
+        } else if (block.has_skip_coded) {
+            if (block.size != size) throw std::runtime_error("Invalid skip_coded block size.");
+        } else {
+            throw std::runtime_error("Internal error: expected coded block.");
+        }
+        return index;
+    }
+
+    void code_pending() {                                // one K1 batch for the whole file
+        if (pending_.empty()) return;
+        size_t bins = 0;
+        for (auto &p : pending_) bins += p.recs.size();
+        batch_holder bh(device_, pending_.size(), bins + 8);
+        for (auto &p : pending_)
+            gpu_check(avr_batch_add_slice_cabac(bh.b, p.recs.data(), p.recs.size(), p.init_states.data(), AVR_MAX_STATES));
+        gpu_check(avr_batch_run(bh.b));
+        for (size_t i = 0; i < pending_.size(); i++) {
+            const uint8_t *bytes; size_t len; int status;
+            gpu_check(avr_batch_get(bh.b, i, &bytes, &len, &status));
+            if (status != AVR_SLICE_OK) throw std::runtime_error("avr: slice status " + std::to_string(status));
+            len = avr_drop_stop_byte(bytes, len);        // cabac_decoder::finish, recode.cpp:1508-1512
+            blocks_[pending_[i].index].out_bytes.assign(reinterpret_cast<const char *>(bytes), len);
+            blocks_[pending_[i].index].done = true;
+        }
+        pending_.clear();
+    }
+
+    struct pending { int index; std::vector<uint16_t> recs; std::vector<uint8_t> init_states; };
+    int device_;
+    Recoded in_;
+    int read_index_ = 0, read_offset_ = 0;
+    std::string read_block_;
+    std::vector<block_state> blocks_;
+    uint64_t surrogate_marker_sequence_number_ = 1;      // :1592
+    int next_coded_block_ = 0;
+    const uint8_t *state_base_ = nullptr;
+    h264_model model_;
+    std::vector<pending> pending_;
+};
+
+// recode.cpp:1601-1640: compress, decompress, compare.  `make_decoder` supplies a fresh stream
+// decoder for each of the two passes (av_decoder is constructed twice there too).
+template <class MakeDecoder>
+int roundtrip(const std::string &original, MakeDecoder make_decoder, std::string *compressed_out, int device = 0) {
+    compressor c(original, device);
+    std::unique_ptr<stream_decoder> d1(make_decoder(&c, nullptr));
+    const std::string compressed = c.run(d1.get());
+    decompressor d(compressed, device);
+    std::unique_ptr<stream_decoder> d2(make_decoder(nullptr, &d));
+    const std::string decompressed = d.run(d2.get());
+    if (compressed_out) *compressed_out = compressed;
+    return original == decompressed ? 0 : 1;
+}
+
+}  // namespace host
+}  // namespace avr

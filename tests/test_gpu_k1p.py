@@ -74,3 +74,21 @@ def test_chunked_full_size_config2_sampled(avr, oracle):
     w.out.zero_()
     w.encode_chunked()
     assert w.results()[0] == again == got
+
+
+def test_batch_api_takes_the_chunked_path_for_long_slices(avr, oracle, monkeypatch):
+    rng = np.random.default_rng(77)
+    slices = [oracle_lib.random_cabac_stream(rng, int(rng.integers(15000, 40000)), 200) for _ in range(12)]
+    slices.append((np.array([0 | (300 << 1), 1 | (1025 << 1)], dtype=np.uint16), np.zeros(200, np.uint8)))   # bad selector
+    want = [oracle.cabac_encode(r, s) for r, s in slices]
+    for force in (None, "serial", "chunked"):
+        if force:
+            monkeypatch.setenv("AVR_K1_PATH", force)
+        with avr.Batch(0, len(slices), sum(len(r) for r, _ in slices) + 8) as b:
+            for r, s in slices:
+                b.add_slice_cabac(r, s)
+            b.run()
+            for i in range(len(slices) - 1):
+                data, status = b.get(i)
+                assert (data, b.get_states(i), status) == want[i], f"path {force} slice {i}"
+            assert b.get(len(slices) - 1)[1] == avr.SLICE_BAD_RECORD

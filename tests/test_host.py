@@ -1,0 +1,198 @@
+"""Host C++ layer (avrecode-ms_amd/csrc/host/): model, range decoder, CABAC bin decoder, .recode
+container, surrogate blocks -- and, on a GPU, the reference's roundtrip (recode.cpp:1601-1640:
+compress -> decompress -> byte-compare) over a file of recorded slices."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host_api.cpp")
+SO = os.path.join(ROOT, "tests", "_host_api.so")
+CSRC = os.path.join(ROOT, "avrecode-ms_amd", "csrc")
+P = oracle_lib.ptr
+
+
+@pytest.fixture(scope="module")
+def host(avr):
+    deps = [SRC, os.path.join(CSRC, "host", "avr_host.h"), os.path.join(CSRC, "host", "avr_recode.h"), avr.LIB_PATH]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-I/opt/rocm/include",
+                        "-D__HIP_PLATFORM_AMD__", "-o", SO, SRC, "-L" + os.path.dirname(avr.LIB_PATH), "-lavrecode_hip",
+                        "-Wl,-rpath,$ORIGIN/../avrecode-ms_amd"], check=True)
+    lib = ctypes.CDLL(SO)
+    for f in ("t_container_reserialize", "t_container_build"):
+        getattr(lib, f).restype = ctypes.c_size_t
+    return lib
+
+
+def test_range_decoder_matches_oracle(host, oracle):
+    rng = np.random.default_rng(3)
+    for t in range(60):
+        recs = oracle_lib.random_range_stream(rng, int(rng.integers(0, 3000)), adaptive=bool(t % 2))
+        data, _ = oracle.range_encode(recs)
+        extra = np.concatenate([recs, np.full(40, (3 << 1) | (5 << 8), dtype=np.uint16)])     # reads past the end too
+        buf = np.frombuffer(data, np.uint8).copy() if data else np.zeros(1, np.uint8)
+        got = np.zeros(extra.size, np.uint8)
+        host.t_range_decode(P(buf), ctypes.c_size_t(len(data)), P(extra), ctypes.c_size_t(extra.size), P(got))
+        assert np.array_equal(got, oracle.range_decode(data, extra))
+        assert np.array_equal(got[:recs.size], recs & 1)
+
+
+def test_cabac_bin_decoder_matches_standard_decoder(host, oracle):
+    rng = np.random.default_rng(4)
+    for t in range(80):
+        recs, states = oracle_lib.random_cabac_stream(rng, int(rng.integers(0, 2500)), int(rng.integers(1, 300)))
+        data, final, _ = oracle.cabac_encode(recs, states)
+        st = np.zeros(1024, np.uint8)
+        st[:states.size] = states
+        buf = np.frombuffer(data, np.uint8).copy()
+        got = np.zeros(recs.size, np.uint8)
+        host.t_cabac_decode(P(buf), ctypes.c_size_t(len(data)), P(recs), ctypes.c_size_t(recs.size), P(st), P(got))
+        assert np.array_equal(got, recs & 1)                      # decodes what cabac::encoder coded
+        assert st[:states.size].tobytes() == final                # and leaves the states the encoder left
+
+
+def test_model_matches_oracle_estimator(host, oracle):
+    rng = np.random.default_rng(5)
+    n = 20000
+    ctx = rng.integers(0, 30, n).astype(np.uint16)
+    sym = (rng.random(n) < 0.3).astype(np.uint8)
+    sig = (rng.random(n) < 0.2).astype(np.uint8)
+    pos, neg, prob = np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint64)
+    host.t_model_trace(P(ctx), P(sym), P(sig), ctypes.c_size_t(n), P(pos), P(neg), P(prob))
+
+    class Est(ctypes.Structure):
+        _fields_ = [("pos", ctypes.c_int), ("neg", ctypes.c_int)]
+    est = {}
+    for i in range(n):
+        e = est.setdefault(int(ctx[i]), Est(1, 1))
+        assert (pos[i], neg[i]) == (e.pos, e.neg)
+        assert prob[i] == oracle.L.avr_oracle_probability(ctypes.c_uint64(1 << 60), ctypes.byref(e))
+        oracle.L.avr_oracle_update(ctypes.byref(e), int(sym[i]), int(sig[i]))
+    assert max(int(p) + int(q) for p, q in zip(pos, neg)) <= 0x60
+
+
+def recoded_message_classes():
+    """recode.proto:1-19 as a dynamic descriptor (protoc is not available here)."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name="recode.proto", syntax="proto2")
+    rec = fd.message_type.add(name="Recoded")
+    meta = rec.nested_type.add(name="Metadata")
+    for i, (nm, ty) in enumerate((("version", F.TYPE_BYTES), ("source_commit", F.TYPE_BYTES), ("binary_sha256", F.TYPE_BYTES),
+                                  ("binary_timestamp", F.TYPE_INT64)), 1):
+        meta.field.add(name=nm, number=i, type=ty, label=F.LABEL_OPTIONAL)
+    blk = rec.nested_type.add(name="Block")
+    for i, (nm, ty) in enumerate((("size", F.TYPE_INT64), ("literal", F.TYPE_BYTES), ("skip_coded", F.TYPE_BOOL),
+                                  ("cabac", F.TYPE_BYTES), ("length_parity", F.TYPE_BOOL), ("last_byte", F.TYPE_BYTES)), 1):
+        blk.field.add(name=nm, number=i, type=ty, label=F.LABEL_OPTIONAL)
+    rec.field.add(name="metadata", number=1, type=F.TYPE_MESSAGE, type_name=".Recoded.Metadata", label=F.LABEL_OPTIONAL)
+    rec.field.add(name="block", number=2, type=F.TYPE_MESSAGE, type_name=".Recoded.Block", label=F.LABEL_REPEATED)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("Recoded"))
+
+
+def test_container_is_bit_exact_with_protobuf(host):
+    Recoded = recoded_message_classes()
+    rng = np.random.default_rng(6)
+    msg = Recoded()
+    has, size, flags, blobs = [], [], [], []
+    for i in range(60):
+        b = msg.block.add()
+        kind = i % 4
+        h, fl, parts = 0, 0, [b"", b"", b""]
+        if kind == 0:                                         # literal (possibly empty: set with a zero gap, recode.cpp:1288)
+            parts[0] = rng.integers(0, 256, int(rng.integers(0, 300)) if i % 8 else 0, dtype=np.uint8).tobytes()
+            b.literal = parts[0]; h |= 2
+        elif kind == 1:                                       # coded block (recode.cpp:1154, 1291-1294, 1101)
+            b.size = int(rng.integers(8, 1 << 40)); h |= 1; size_i = b.size
+            parts[1] = rng.integers(0, 256, int(rng.integers(1, 500)), dtype=np.uint8).tobytes()
+            b.cabac = parts[1]; h |= 8
+            b.length_parity = bool(i & 4); h |= 16; fl |= 2 if b.length_parity else 0
+            parts[2] = bytes([int(rng.integers(0, 256))]); b.last_byte = parts[2]; h |= 32
+        elif kind == 2:                                       # skipped slice (recode.cpp:1299-1301)
+            b.skip_coded = True; h |= 4; fl |= 1
+            b.size = int(rng.integers(0, 8)); h |= 1
+        else:                                                 # size only with a large value: varint lengths
+            b.size = (1 << 62) + i; h |= 1
+        has.append(h); flags.append(fl); size.append(b.size if h & 1 else 0); blobs.append(parts)
+    want = msg.SerializeToString()
+    flat = b"".join(b"".join(p) for p in blobs)
+    off = np.zeros(3 * len(blobs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for p in blobs for x in p])
+    out = np.zeros(len(want) + 64, np.uint8)
+    fb = np.frombuffer(flat, np.uint8).copy()
+    n = host.t_container_build(ctypes.c_size_t(len(blobs)), P(np.array(has, np.uint8)), P(np.array(size, np.int64)),
+                               P(np.array(flags, np.uint8)), P(fb), P(off), P(out), ctypes.c_size_t(out.size))
+    assert out[:n].tobytes() == want                          # writer == protobuf's C++/Python serializer
+    # reader: parse protobuf's bytes (plus an unknown field and the never-set metadata) and write them back
+    msg.metadata.version = b"x"
+    blob = msg.SerializeToString() + bytes([7 << 3 | 0, 5])   # field 7, varint: unknown, must be skipped
+    back = np.zeros(len(want) + 64, np.uint8)
+    nb = ctypes.c_uint32(0)
+    bb = np.frombuffer(blob, np.uint8).copy()
+    n2 = host.t_container_reserialize(P(bb), ctypes.c_size_t(len(blob)), P(back), ctypes.c_size_t(back.size), ctypes.byref(nb))
+    assert nb.value == 60 and back[:n2].tobytes() == want
+    assert host.t_container_reserialize(P(bb), ctypes.c_size_t(len(want) - 3), P(back), ctypes.c_size_t(back.size), ctypes.byref(nb)) == 0
+
+
+def test_surrogate_blocks(host):
+    # recode.cpp:1534-1551: base-255 digits + 1 (no zero bytes), padded with 'X'
+    for seq, size in ((1, 8), (254, 20), (255, 9), (255 * 255 + 7, 64)):
+        out = np.zeros(size, np.uint8)
+        host.t_surrogate(ctypes.c_uint64(seq), ctypes.c_size_t(size), P(out))
+        n, want = seq, []
+        for _ in range(8):
+            want.append(n % 255 + 1)
+            n //= 255
+        assert out[:8].tolist() == want and (out[8:] == ord("X")).all() and 0 not in out
+
+
+@pytest.mark.gpu
+def test_roundtrip_of_a_file_of_recorded_slices(host, oracle, avr):
+    """recode.cpp:1601-1640 end to end: K2 on the way in, K3 (CPU) + K1 on the way out."""
+    rng = np.random.default_rng(8)
+    file_parts, offsets, sizes, recs_all, states_all, escaped = [], [], [], [], [], []
+    pos = 0
+    for i in range(30):
+        lit = rng.integers(0, 256, int(rng.integers(0, 400)), dtype=np.uint8).tobytes()        # container / NAL headers
+        n = int(rng.integers(0, 6000)) if i % 9 else int(rng.integers(0, 4))                   # a few tiny slices (< 8 bytes)
+        recs, st = oracle_lib.random_cabac_stream(rng, n, int(rng.integers(1, 400)))
+        st1024 = np.zeros(1024, np.uint8)
+        st1024[:st.size] = st
+        payload, _, status = oracle.cabac_encode(recs, st1024)                                  # the slice's H.264 bytes
+        assert status == 0
+        file_parts += [lit, payload]
+        offsets.append(pos + len(lit)); sizes.append(len(payload)); pos += len(lit) + len(payload)
+        recs_all.append(recs); states_all.append(st1024); escaped.append(1 if i == 11 else 0)
+    file_parts.append(rng.integers(0, 256, 123, dtype=np.uint8).tobytes())
+    data = b"".join(file_parts)
+    rec_off = np.zeros(len(recs_all) + 1, np.uint64)
+    rec_off[1:] = np.cumsum([len(r) for r in recs_all])
+    fbuf = np.frombuffer(data, np.uint8).copy()
+    comp = np.zeros(len(data) * 2 + 4096, np.uint8)
+    comp_len = ctypes.c_size_t(0)
+    stats = np.zeros(2, np.uint64)
+    err = ctypes.create_string_buffer(512)
+    rc = host.t_roundtrip(P(fbuf), ctypes.c_size_t(len(data)), ctypes.c_size_t(len(recs_all)), P(np.array(offsets, np.uint64)),
+                          P(np.array(sizes, np.uint64)), P(rec_off), P(np.concatenate(recs_all).astype(np.uint16)),
+                          P(np.concatenate(states_all)), P(np.array(escaped, np.uint8)), P(comp), ctypes.c_size_t(comp.size),
+                          ctypes.byref(comp_len), P(stats), err, ctypes.c_size_t(512))
+    assert rc == 0, err.value.decode()                      # "Compress-decompress roundtrip succeeded"
+    assert stats[0] == 0                                     # every bin the hooks returned is the bin that was coded
+    n_hooked = sum(1 for s, e in zip(sizes, escaped) if s >= 8 and not e)
+    assert stats[1] == 2 * n_hooked                          # compress pass + decompress pass; tiny / escaped slices are skipped
+    # the container holds literal, cabac and skip blocks as the reference would have written them
+    Recoded = recoded_message_classes()
+    msg = Recoded()
+    msg.ParseFromString(comp[:comp_len.value].tobytes())
+    kinds = [("literal" if b.HasField("literal") else "cabac" if b.HasField("cabac") else "skip") for b in msg.block]
+    assert kinds.count("cabac") == n_hooked and kinds.count("skip") == len(sizes) - n_hooked and kinds[-1] == "literal"
+    coded = [b for b in msg.block if b.HasField("cabac")]
+    assert all(b.size >= 8 and b.HasField("length_parity") and len(b.last_byte) == 1 for b in coded)
