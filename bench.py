@@ -143,6 +143,8 @@ def main():
                     help="K1 mapping: one lane per slice, or the intra-slice parallel kernels (auto: chunked "
                          "when the batch has too few slices to fill the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N>1 (nccl = RCCL; gloo lets several ranks rehearse on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -153,13 +155,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available() or avr.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.backend == "gloo":                       # rehearsal: ranks may share a GPU
+        local_rank %= torch.cuda.device_count()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
     kind = avr.KIND_CABAC if args.kind == "cabac" else avr.KIND_RANGE
 
     n_slices = args.slices or DEFAULT_SLICES[args.workload]
@@ -195,7 +203,7 @@ def main():
 
     out_bytes = w.output_bytes()
     status_bad = int((w.status != 0).sum().item())
-    t_max, total_bytes = reduce_timing(dist if world > 1 else None, elapsed, out_bytes * args.steps, dev)
+    t_max, total_bytes = reduce_timing(dist if world > 1 else None, elapsed, out_bytes * args.steps, red_dev)
 
     if rank == 0:
         algo = w.algorithmic_bytes()
