@@ -103,6 +103,12 @@ SIGNATURES = {
     "avr_cabac_encode_chunked_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                                 c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_void_p]),
+    "avr_cabac_resolve_workspace_bytes": (c_size_t, [c_size_t, c_size_t, c_void_p]),
+    "avr_cabac_resolve_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
+                                         c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "avr_cabac_resolved_workspace_bytes": (c_size_t, [c_size_t, c_void_p]),
+    "avr_cabac_encode_resolved_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,
+                                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "avr_cabac_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "avr_range_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -443,6 +443,51 @@ int avr_cabac_encode_chunked_device(int device, void *stream, const uint16_t *re
     return AVR_OK;
 }
 
+static int check_plan(const avr_chunk_plan *plan, size_t n_slices, bool need_blocks) {
+    if (!plan || (n_slices && (!plan->res_off || !plan->chunk_base || !plan->chunk_slice || !plan->dig_off ||
+                               (need_blocks && (!plan->blk_base || !plan->blk_slice)))))
+        return fail(AVR_ERR_INVALID, "null plan pointer");
+    return AVR_OK;
+}
+
+size_t avr_cabac_resolve_workspace_bytes(size_t n_slices, size_t n_states, const avr_chunk_plan *plan) {
+    if (!plan || n_states > AVR_MAX_STATES) return 0;
+    return avr::k1p_resolve_workspace_bytes(n_slices, uint32_t(n_states), plan);
+}
+
+int avr_cabac_resolve_device(int device, void *stream, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                             size_t n_slices, const uint8_t *init_states, size_t n_states, const avr_chunk_plan *plan,
+                             void *workspace, size_t workspace_bytes, uint8_t *codes, int32_t *status, uint8_t *final_states) {
+    if (int rc = check_common(rec_off, n_bins, codes, n_slices)) return rc;
+    if (n_states > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "n_states %zu > %d", n_states, AVR_MAX_STATES);
+    if (int rc = check_plan(plan, n_slices, true)) return rc;
+    if (n_slices && (!workspace || !status)) return fail(AVR_ERR_INVALID, "null workspace / status");
+    if (workspace_bytes < avr::k1p_resolve_workspace_bytes(n_slices, uint32_t(n_states), plan))
+        return fail(AVR_ERR_CAPACITY, "workspace smaller than avr_cabac_resolve_workspace_bytes()");
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_k1p_resolve(static_cast<hipStream_t>(stream), recs, rec_off, n_bins, uint32_t(n_slices), init_states,
+                                    uint32_t(n_states), plan, workspace, codes, status, final_states));
+    return AVR_OK;
+}
+
+size_t avr_cabac_resolved_workspace_bytes(size_t n_slices, const avr_chunk_plan *plan) {
+    return plan ? avr::k1p_code_workspace_bytes(n_slices, plan) : 0;
+}
+
+int avr_cabac_encode_resolved_device(int device, void *stream, const uint8_t *codes, const uint32_t *n_bins, size_t n_slices,
+                                     const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes, uint8_t *out,
+                                     const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
+    if (int rc = check_common(codes, n_bins, out_off, n_slices)) return rc;
+    if (int rc = check_plan(plan, n_slices, false)) return rc;
+    if (n_slices && (!workspace || !status)) return fail(AVR_ERR_INVALID, "null workspace / status");
+    if (workspace_bytes < avr::k1p_code_workspace_bytes(n_slices, plan))
+        return fail(AVR_ERR_CAPACITY, "workspace smaller than avr_cabac_resolved_workspace_bytes()");
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_k1p_code(static_cast<hipStream_t>(stream), codes, n_bins, uint32_t(n_slices), plan, workspace, out, out_off,
+                                 out_len, status));
+    return AVR_OK;
+}
+
 int avr_cabac_encode_slices_device(int device, void *stream, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
                                    const uint32_t *order, size_t n_slices, const uint8_t *init_states, size_t n_states,
                                    uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status, uint8_t *final_states) {

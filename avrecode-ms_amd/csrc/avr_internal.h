@@ -43,6 +43,14 @@ hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
                       uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
                       void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
                       uint8_t *final_states);
+size_t k1p_resolve_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl);
+hipError_t launch_k1p_resolve(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                              uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
+                              void *workspace, uint8_t *codes, int32_t *status, uint8_t *final_states);
+size_t k1p_code_workspace_bytes(size_t n_slices, const avr_chunk_plan *pl);
+hipError_t launch_k1p_code(hipStream_t s, const uint8_t *codes, const uint32_t *n_bins, uint32_t n_slices,
+                           const avr_chunk_plan *pl, void *workspace, uint8_t *out, const uint64_t *out_off,
+                           uint32_t *out_len, int32_t *status);
 hipError_t launch_synth_slices(hipStream_t s, int workload, uint32_t scale, uint64_t seed, uint64_t first_slice,
                                int kind, uint32_t n_slices, const uint64_t *rec_off, uint16_t *recs,
                                uint8_t *init_states, uint32_t n_states);

@@ -124,7 +124,8 @@ AVR_HD void for_codes(const uint8_t *res, uint32_t from, uint32_t n, F &&f) {
     }
 }
 
-AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const uint32_t *rows, Stretch *o) {
+AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const uint32_t *rows, uint32_t max_stretch,
+                       Stretch *o) {
     const uint32_t lo = chunk * kChunk, limit = lo + kChunk;
     uint32_t R[4], T[4] = {0, 0, 0, 0};
     uint32_t i;
@@ -169,7 +170,7 @@ AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const uin
             if (closing) o->exit_q = uint8_t(((Rm >> 6) & 3) * 0x55u);
             Tm += step_range(c, rows, &Rm);
             if (closing) { end = idx + 1; return true; }
-            if (idx - lo > kMaxStretch) { o->too_long = 1; end = idx + 1; return true; }
+            if (idx - lo > max_stretch) { o->too_long = 1; end = idx + 1; return true; }
             return false;
         });
         R[0] = R[1] = R[2] = R[3] = Rm;

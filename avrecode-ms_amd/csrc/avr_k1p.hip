@@ -105,11 +105,14 @@ __global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, uint32_t *hist, uint3
 __global__ __launch_bounds__(64) void k_k1p_scatter(Plan p, const int32_t *status, const uint32_t *boff,
                                                     const uint32_t *run_start, uint8_t *sorted, uint32_t *pos,
                                                     uint32_t key_bits) {
-    __shared__ uint32_t cnt[AVR_MAX_STATES];                     // next local position of each context
-    __shared__ uint32_t delta[AVR_MAX_STATES];                   // global position - local position
-    __shared__ uint16_t kbuf[kSortBlock];                        // context of every locally sorted bin
-    __shared__ uint8_t lbuf[kSortBlock];                         // the bins, locally sorted
-    const uint32_t b = blockIdx.x, s = p.blk_slice[b], nk = p.n_states, lane = threadIdx.x;
+    // LDS (dynamic, sized by the number of contexts so that more blocks fit a CU):
+    extern __shared__ uint32_t scatter_lds[];
+    const uint32_t nk = p.n_states, nk_pad = (nk + 63) & ~63u;
+    uint32_t *cnt = scatter_lds;                                 // next local position of each context
+    uint32_t *delta = cnt + nk_pad;                              // global position - local position
+    uint16_t *kbuf = reinterpret_cast<uint16_t *>(delta + nk_pad);   // context of every locally sorted bin
+    uint8_t *lbuf = reinterpret_cast<uint8_t *>(kbuf + kSortBlock);  // the bins, locally sorted
+    const uint32_t b = blockIdx.x, s = p.blk_slice[b], lane = threadIdx.x;
     if (status[s] != AVR_SLICE_OK) return;
     const bool last_block = b + 1 == p.blk_base[s + 1];
     const uint32_t *g0 = boff + size_t(b) * nk;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void k_k1p_gather(Plan p, const uint8_t *sorte
 // ------------------------------------------------------------------ phases B1, B2, C
 
 __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, const uint8_t *res,
-                                                const int32_t *status, Stretch *st) {
+                                                const int32_t *status, Stretch *st, uint32_t max_stretch) {
     __shared__ uint32_t rows[64];
     if (threadIdx.x < 64) rows[threadIdx.x] = d_tables.packed[2 * threadIdx.x][0];
     __syncthreads();
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, c
     const uint32_t slice = p.chunk_slice[gc];
     if (status[slice] != AVR_SLICE_OK) { st[gc].first = kNone; st[gc].too_long = 0; return; }
     Stretch o;
-    b1_stretch(res + p.res_off[slice], p.n_bins[slice], gc - p.chunk_base[slice], rows, &o);
+    b1_stretch(res + p.res_off[slice], p.n_bins[slice], gc - p.chunk_base[slice], rows, max_stretch, &o);
     st[gc] = o;
 }
 
@@ -527,16 +530,19 @@ __global__ __launch_bounds__(256) void k_k1p_d(Plan p, const SliceTotals *tot, c
             uint32_t cin = carry_in;
             for (uint32_t k = 256; k-- > 0;) {
                 seg_cin[k] = cin;
-                cin = seg_g[k] | (seg_p[k] & cin);       // a carry leaves the segment if it makes one, or passes one on
+                // digit sums overlap where stretches meet, so carries are small integers, not bits: a
+                // segment sends on what it made itself, plus one if it is all ones and receives any
+                cin = seg_g[k] + ((seg_p[k] && cin) ? 1u : 0u);
             }
             sh_carry = cin;                              // into the next (higher-order) tile
         }
         __syncthreads();
         if (seg_cin[t]) {
-            for (uint32_t i = b; i-- > a;) {
-                const uint32_t v = dig[i] + 1;
+            uint32_t c2 = seg_cin[t];
+            for (uint32_t i = b; i-- > a && c2;) {
+                const uint32_t v = dig[i] + c2;
                 dig[i] = v & 0xffffu;
-                if (v <= 0xffffu) break;
+                c2 = v >> 16;
             }
         }
         __syncthreads();
@@ -564,34 +570,26 @@ size_t k1p_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_p
                   up256(n_slices * sizeof(SliceTotals)) + up256(pl->dig_total * 4 + 16));
 }
 
-hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
-                      uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
-                      void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
-                      uint8_t *final_states) {
-    if (n_slices == 0) return hipSuccess;
-    uint8_t *w = static_cast<uint8_t *>(workspace);
-    uint8_t *res = w;                                        w += up256(pl->res_total + 32);
+// Phase A: records + initial states -> resolved codes `res` (slice i at res + res_off[i]).
+// `w` is workspace for the sort (sorted bins, positions, histograms, run starts, segments).
+static hipError_t launch_resolve(hipStream_t s, const Plan &p, uint32_t n_slices, const uint8_t *init_states,
+                                 const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, int32_t *status, uint8_t *final_states) {
+    const uint32_t n_states = p.n_states;
     uint8_t *sorted = w;                                     w += up256(pl->res_total + 32);
     uint32_t *pos = reinterpret_cast<uint32_t *>(w);         w += up256(4 * (pl->res_total + 32));
     uint32_t *hist = reinterpret_cast<uint32_t *>(w);        w += up256(uint64_t(pl->total_blocks) * n_states * 4 + 16);
     uint32_t *run_start = reinterpret_cast<uint32_t *>(w);   w += up256(n_slices * uint64_t(n_states + 1) * 4 + 16);
     Seg *seg = reinterpret_cast<Seg *>(w);                   w += up256(uint64_t(pl->total_chunks) * sizeof(Seg));
-    uint8_t *entry = w;                                      w += up256(uint64_t(pl->total_chunks) + 16);
-    Stretch *st = reinterpret_cast<Stretch *>(w);            w += up256(uint64_t(pl->total_chunks) * sizeof(Stretch));
-    Entry *en = reinterpret_cast<Entry *>(w);                w += up256(uint64_t(pl->total_chunks) * sizeof(Entry));
-    SliceTotals *tot = reinterpret_cast<SliceTotals *>(w);   w += up256(n_slices * sizeof(SliceTotals));
-    uint32_t *S = reinterpret_cast<uint32_t *>(w);
-    const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
-                 pl->dig_off, n_states};
+    uint8_t *entry = w;
     uint32_t key_bits = 0;
     while ((1u << key_bits) < n_states) key_bits++;
-
     const uint32_t chunk_blocks = (pl->total_chunks + 255) / 256;
     if (n_states > 0) {
         hipLaunchKernelGGL(k_k1p_hist, dim3(pl->total_blocks), dim3(256), 0, s, p, status, hist);
         hipLaunchKernelGGL(k_k1p_scan, dim3(n_slices), dim3(1024), 0, s, p, hist, run_start);
-        hipLaunchKernelGGL(k_k1p_scatter, dim3(pl->total_blocks), dim3(64), 0, s, p, status, hist, run_start, sorted, pos,
-                           key_bits);
+        const uint32_t scatter_lds = 8 * ((n_states + 63) & ~63u) + 3 * kSortBlock;
+        hipLaunchKernelGGL(k_k1p_scatter, dim3(pl->total_blocks), dim3(64), scatter_lds, s, p, status, hist, run_start, sorted,
+                           pos, key_bits);
         hipLaunchKernelGGL(k_k1p_spec, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
                            sorted, seg);
         hipLaunchKernelGGL(k_k1p_link, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
@@ -600,16 +598,76 @@ hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
                            sorted, seg, entry, final_states);
     }
     hipLaunchKernelGGL(k_k1p_gather, dim3(pl->total_chunks), dim3(256), 0, s, p, sorted, pos, res, status);
-    hipLaunchKernelGGL(k_k1p_b1, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, status, st);
+    return hipGetLastError();
+}
+
+// Phases B-D: resolved codes -> bytes.  `w` is workspace for stretches, entries, totals, digit sums.
+static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, const avr_chunk_plan *pl, uint8_t *w,
+                              const uint8_t *res, uint32_t max_stretch, uint8_t *out, const uint64_t *out_off,
+                              uint32_t *out_len, int32_t *status) {
+    Stretch *st = reinterpret_cast<Stretch *>(w);            w += up256(uint64_t(pl->total_chunks) * sizeof(Stretch));
+    Entry *en = reinterpret_cast<Entry *>(w);                w += up256(uint64_t(pl->total_chunks) * sizeof(Entry));
+    SliceTotals *tot = reinterpret_cast<SliceTotals *>(w);   w += up256(n_slices * sizeof(SliceTotals));
+    uint32_t *S = reinterpret_cast<uint32_t *>(w);
+    const uint32_t chunk_blocks = (pl->total_chunks + 255) / 256;
+    hipLaunchKernelGGL(k_k1p_b1, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, status, st, max_stretch);
     hipLaunchKernelGGL(k_k1p_b2, dim3(n_slices), dim3(256), 0, s, p, status, st, en, tot);
     hipLaunchKernelGGL(k_k1p_zero, dim3(n_slices), dim3(256), 0, s, p, tot, S);
     hipLaunchKernelGGL(k_k1p_c, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
     hipLaunchKernelGGL(k_k1p_d, dim3(n_slices), dim3(256), 0, s, p, tot, S, out, out_off, out_len, status);
-    hipError_t e = hipGetLastError();
+    return hipGetLastError();
+}
+
+static inline uint64_t resolve_ws_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl) {
+    return up256(pl->res_total + 32) + up256(4 * (pl->res_total + 32)) + up256(uint64_t(pl->total_blocks) * n_states * 4 + 16) +
+           up256(n_slices * uint64_t(n_states + 1) * 4 + 16) + up256(uint64_t(pl->total_chunks) * sizeof(Seg)) +
+           up256(uint64_t(pl->total_chunks) + 16);
+}
+
+hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                      uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
+                      void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
+                      uint8_t *final_states) {
+    if (n_slices == 0) return hipSuccess;
+    uint8_t *w = static_cast<uint8_t *>(workspace);
+    uint8_t *res = w;                                        w += up256(pl->res_total + 32);
+    const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
+                 pl->dig_off, n_states};
+    hipError_t e = launch_resolve(s, p, n_slices, init_states, pl, w, res, status, final_states);
+    if (e != hipSuccess) return e;
+    w += resolve_ws_bytes(n_slices, n_states, pl);
+    e = launch_code(s, p, n_slices, pl, w, res, kMaxStretch, out, out_off, out_len, status);
     if (e != hipSuccess) return e;
     // slices the scheme declined (status AVR_SLICE_RETRY_SERIAL) are coded by the serial kernel
     return launch_cabac_encode(false, s, recs, rec_off, n_bins, nullptr, n_slices, init_states, n_states, out, out_off,
                                out_len, status, nullptr, AVR_SLICE_RETRY_SERIAL);
+}
+
+// The two stages on their own: phase A into a caller-owned code buffer ...
+size_t k1p_resolve_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl) {
+    return size_t(resolve_ws_bytes(n_slices, n_states, pl));
+}
+hipError_t launch_k1p_resolve(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                              uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
+                              void *workspace, uint8_t *codes, int32_t *status, uint8_t *final_states) {
+    if (n_slices == 0) return hipSuccess;
+    const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
+                 pl->dig_off, n_states};
+    return launch_resolve(s, p, n_slices, init_states, pl, static_cast<uint8_t *>(workspace), codes, status, final_states);
+}
+// ... and phases B-D from resolved codes (no stretch is ever declined here: there are no records to
+// fall back to, so a stretch without an LPS is simply walked to its end by one lane)
+size_t k1p_code_workspace_bytes(size_t n_slices, const avr_chunk_plan *pl) {
+    return size_t(up256(uint64_t(pl->total_chunks) * sizeof(Stretch)) + up256(uint64_t(pl->total_chunks) * sizeof(Entry)) +
+                  up256(n_slices * sizeof(SliceTotals)) + up256(pl->dig_total * 4 + 16));
+}
+hipError_t launch_k1p_code(hipStream_t s, const uint8_t *codes, const uint32_t *n_bins, uint32_t n_slices,
+                           const avr_chunk_plan *pl, void *workspace, uint8_t *out, const uint64_t *out_off,
+                           uint32_t *out_len, int32_t *status) {
+    if (n_slices == 0) return hipSuccess;
+    const Plan p{nullptr, nullptr, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
+                 pl->dig_off, 0};
+    return launch_code(s, p, n_slices, pl, static_cast<uint8_t *>(workspace), codes, 0xffffffffu, out, out_off, out_len, status);
 }
 
 }  // namespace avr

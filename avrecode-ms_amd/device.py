@@ -192,6 +192,39 @@ class DeviceWorkload:
             self.out.data_ptr(), self.out_off.data_ptr(), self.out_len.data_ptr(), self.status.data_ptr(),
             self.final_states.data_ptr() if self.final_states is not None else None))
 
+    def resolve(self):
+        """Stage 1 of K1p alone: resolved codes (uint8 tensor, slice i at res_off[i]) on the device."""
+        import torch
+        recs, rec_off = self._slice_major()
+        p = self._chunk_plan()
+        L = lib()
+        if "codes" not in p:
+            n = L.avr_cabac_resolve_workspace_bytes(self.n_slices, self.n_states, ctypes.byref(p["plan"]))
+            p["ws1"] = torch.empty(n + 256, dtype=torch.uint8, device=self.n_bins.device)
+            p["ws1_bytes"] = n
+            p["codes"] = torch.empty(p["plan"].res_total + 32 + 256, dtype=torch.uint8, device=self.n_bins.device)
+        al = lambda t: (t.data_ptr() + 255) // 256 * 256
+        _check(L.avr_cabac_resolve_device(
+            self.device_index, _stream_ptr(torch), recs.data_ptr(), rec_off.data_ptr(), self.n_bins.data_ptr(), self.n_slices,
+            self.init_states.data_ptr(), self.n_states, ctypes.byref(p["plan"]), al(p["ws1"]), p["ws1_bytes"], al(p["codes"]),
+            self.status.data_ptr(), self.final_states.data_ptr() if self.final_states is not None else None))
+        off = al(p["codes"]) - p["codes"].data_ptr()
+        return p["codes"][off:off + p["plan"].res_total + 32]
+
+    def encode_resolved(self, codes):
+        """Stage 2 of K1p alone: arithmetic coding from resolved codes (same bytes as encode())."""
+        import torch
+        p = self._chunk_plan()
+        L = lib()
+        if "ws2" not in p:
+            n = L.avr_cabac_resolved_workspace_bytes(self.n_slices, ctypes.byref(p["plan"]))
+            p["ws2"] = torch.empty(n + 256, dtype=torch.uint8, device=self.n_bins.device)
+            p["ws2_bytes"] = n
+        _check(L.avr_cabac_encode_resolved_device(
+            self.device_index, _stream_ptr(torch), codes.data_ptr(), self.n_bins.data_ptr(), self.n_slices,
+            ctypes.byref(p["plan"]), (p["ws2"].data_ptr() + 255) // 256 * 256, p["ws2_bytes"], self.out.data_ptr(),
+            self.out_off.data_ptr(), self.out_len.data_ptr(), self.status.data_ptr()))
+
     def encode_slice_major(self):
         """Same result from the slice-major layout (only for workloads built with from_host)."""
         import torch

@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--path", default="auto", choices=["auto", "serial", "chunked"],
                     help="K1 mapping: one lane per slice, or the intra-slice parallel kernels (auto: chunked "
                          "when the batch has too few slices to fill the chip)")
+    ap.add_argument("--records", default="bins", choices=["bins", "resolved"],
+                    help="bins: (bin, context) records + state tables, the full K1 (default); resolved: time only the "
+                         "arithmetic-coding stage of K1p from (bin, state) codes resolved beforehand")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL; gloo lets several ranks rehearse on one GPU)")
@@ -180,6 +183,12 @@ def main():
     if kind != avr.KIND_CABAC:
         path = "serial"
     step = w.encode_chunked if path == "chunked" else w.encode
+    if args.records == "resolved":
+        if kind != avr.KIND_CABAC:
+            raise SystemExit("--records resolved applies to the CABAC kernel")
+        path = "chunked-stage2"
+        codes = w.resolve()                  # untimed: the recorder is assumed to have produced the codes
+        step = lambda: w.encode_resolved(codes)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -207,6 +216,8 @@ def main():
 
     if rank == 0:
         algo = w.algorithmic_bytes()
+        if args.records == "resolved":       # 1 byte per bin in, no state tables
+            algo = w.total_bins + out_bytes + 16 * n_slices
         achieved = algo / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -224,7 +235,7 @@ def main():
             "dtype": "u32" if kind == avr.KIND_CABAC else "u64", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[args.workload], "kernel": "K1 cabac_encode" if kind == avr.KIND_CABAC else "K2 range_encode",
                        "slices_per_gpu": n_slices, "bins_per_gpu": w.total_bins, "h264_bytes_per_gpu": out_bytes,
-                       "n_states": w.n_states, "layout": "wave-interleaved tiles", "path": path, "parallelism": f"slice-sharded x{world}"},
+                       "n_states": w.n_states, "layout": "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": ("K1p: k_k1p_{hist,scan,scatter,spec,link,chain,gather,b1,b2,zero,c,d} (one step = 13 launches; "

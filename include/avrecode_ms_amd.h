@@ -201,6 +201,36 @@ int avr_cabac_encode_chunked_device(int device, void *stream,
                                     uint8_t *out, const uint64_t *out_off,
                                     uint32_t *out_len, int32_t *status, uint8_t *final_states);
 
+/* The two stages of K1p on their own.
+ *
+ * Stage 1, avr_cabac_resolve_device: context-state resolution (phase A).  Writes one RESOLVED CODE
+ * per bin, slice i at codes + res_off[i] (codes must hold res_total + 32 bytes, 256-byte aligned):
+ *     (state << 1) | bin   context bin met in state = 2*pStateIdx + valMPS <= 125
+ *     252 | bin            bypass bin
+ *     255 - bin            put_terminate(bin) (and a context bin at pStateIdx 63 with symbol bin)
+ * i.e. exactly the inputs cabac::encoder::put takes -- (symbol, *state) -- per bin (cabac_code.h:33).
+ *
+ * Stage 2, avr_cabac_encode_resolved_device: the arithmetic coding (phases B-D) from resolved codes.
+ * A hook adapter that tracks *state itself -- it has to keep libavcodec's state bytes current anyway,
+ * cabac_code.h:43-47 -- can record resolved codes directly with the AVR_CODE_* macros and skip stage 1.
+ * The plan is the one of avr_cabac_encode_chunked_device (blk_* unused by stage 2). */
+#define AVR_CODE_CONTEXT(state, bin)  ((state) >= 126 ? 255 - (((bin) ^ (state)) & 1) : (((state) << 1) | (bin)))
+#define AVR_CODE_BYPASS(bin)          (252 | (bin))
+#define AVR_CODE_TERMINATE(bin)       (255 - (bin))
+size_t avr_cabac_resolve_workspace_bytes(size_t n_slices, size_t n_states, const avr_chunk_plan *plan);
+int avr_cabac_resolve_device(int device, void *stream,
+                             const uint16_t *recs, const uint64_t *rec_off,
+                             const uint32_t *n_bins, size_t n_slices,
+                             const uint8_t *init_states, size_t n_states,
+                             const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes,
+                             uint8_t *codes, int32_t *status, uint8_t *final_states);
+size_t avr_cabac_resolved_workspace_bytes(size_t n_slices, const avr_chunk_plan *plan);
+int avr_cabac_encode_resolved_device(int device, void *stream,
+                                     const uint8_t *codes, const uint32_t *n_bins, size_t n_slices,
+                                     const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes,
+                                     uint8_t *out, const uint64_t *out_off,
+                                     uint32_t *out_len, int32_t *status);
+
 /* Variants that read the slice-major layout directly (one 16-byte load per lane per 8 bins,
  * uncoalesced across lanes); kept for the layout comparison in DESIGN.md and for tests.  The
  * padding records up to each slice's next multiple of 8 must be no-op records. */

@@ -53,7 +53,7 @@ size_t k1p_emul_encode_resolved(const uint8_t *res, size_t n, uint8_t *out, size
     const uint32_t n_chunks = n ? uint32_t((n + kChunk - 1) / kChunk) : 1;
     std::vector<Stretch> st(n_chunks);
     std::vector<Entry> en(n_chunks);
-    for (uint32_t c = 0; c < n_chunks; c++) b1_stretch(res, uint32_t(n), c, rows, &st[c]);
+    for (uint32_t c = 0; c < n_chunks; c++) b1_stretch(res, uint32_t(n), c, rows, kMaxStretch, &st[c]);
     SliceTotals tot;
     b2_chain(st.data(), n_chunks, en.data(), &tot);
     const uint32_t nd = ref_digits(tot.t_total);

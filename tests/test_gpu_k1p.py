@@ -92,3 +92,46 @@ def test_batch_api_takes_the_chunked_path_for_long_slices(avr, oracle, monkeypat
                 data, status = b.get(i)
                 assert (data, b.get_states(i), status) == want[i], f"path {force} slice {i}"
             assert b.get(len(slices) - 1)[1] == avr.SLICE_BAD_RECORD
+
+
+def test_two_stage_form_resolved_codes(avr, oracle):
+    """Stage 1 (state resolution) and stage 2 (arithmetic coding from resolved codes) on their own."""
+    import torch
+    w = avr.DeviceWorkload.synth(2, 40, 0, 0, 60)
+    w.encode()
+    want, _ = w.results()
+    codes = w.resolve()
+    # codes are (state << 1 | bin) etc.: check a slice against a CPU state walk
+    nb = w.n_bins.cpu().numpy()
+    res_off = w._plan["tensors"]["res_off"].cpu().numpy()
+    cfg, nbh, off, recs, states = host_synth(avr, 2, 40, 0, 60)
+    _, mlps = avr.cabac_tables()
+    host = codes.cpu().numpy()
+    for s in (0, 39):
+        st = states[s * cfg.n_states:(s + 1) * cfg.n_states].copy()
+        r = recs[int(off[s]):int(off[s]) + int(nb[s])]
+        exp = np.zeros(r.size, np.uint8)
+        for i, rec in enumerate(r):
+            b, sel = int(rec) & 1, int(rec) >> 1
+            if sel < 1024:
+                exp[i] = (st[sel] << 1) | b
+                st[sel] = mlps[128 + st[sel]] if b == (st[sel] & 1) else mlps[127 - st[sel]]
+            else:
+                exp[i] = (252 | b) if sel == 1024 else 255 - b
+        assert np.array_equal(host[int(res_off[s]):int(res_off[s]) + r.size], exp), f"slice {s}"
+    w.out.zero_(); w.out_len.zero_()
+    w.encode_resolved(codes)
+    got, status = w.results()
+    assert not any(status) and got == want
+    # a stream with no LPS at all (bypass only): stage 2 has no serial kernel to fall back to and walks it
+    n = 30000
+    byp = (np.arange(n) & 1).astype(np.uint8) | 252
+    wl = avr.DeviceWorkload.from_host(0, [((np.arange(n) & 1) | (1024 << 1)).astype(np.uint16)], [np.zeros(4, np.uint8)], 0)
+    plan = wl._chunk_plan()
+    codes2 = torch.zeros(plan["plan"].res_total + 64, dtype=torch.uint8, device="cuda")
+    base = (codes2.data_ptr() + 255) // 256 * 256 - codes2.data_ptr()
+    codes2[base:base + n] = torch.from_numpy(byp).cuda()
+    codes2[base + n:base + n + 32] = 252
+    wl.encode_resolved(codes2[base:])
+    got2, st2 = wl.results()
+    assert st2 == [0] and got2[0] == oracle.cabac_encode(((np.arange(n) & 1) | (1024 << 1)).astype(np.uint16), np.zeros(4, np.uint8))[0]
