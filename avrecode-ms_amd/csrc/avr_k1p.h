@@ -124,6 +124,29 @@ AVR_HD void for_codes(const uint8_t *res, uint32_t from, uint32_t n, F &&f) {
     }
 }
 
+// The same for codes that all get the same treatment: g(code) for every code of res[from .. to), no
+// index, no early exit.  Whole 16-byte groups run without per-code bounds tests.
+template <class G>
+AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g) {
+    if (from >= to) return;
+    const uint32_t head_end = ((from + 15) & ~15u) < to ? ((from + 15) & ~15u) : to;
+    for_codes(res, from, head_end, [&](uint32_t, uint32_t c) { g(c); return false; });
+    uint32_t base = head_end;
+    for (; base + 16 <= to; base += 16) {
+        const U4 v = *reinterpret_cast<const U4 *>(res + base);
+        uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t d = w0;
+            w0 = w1; w1 = w2; w2 = w3;
+            g(d & 0xffu); g((d >> 8) & 0xffu); g((d >> 16) & 0xffu); g(d >> 24);
+        }
+    }
+    if (base < to) for_codes(res, base, to, [&](uint32_t, uint32_t c) { g(c); return false; });
+}
+
 AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const uint32_t *rows, uint32_t max_stretch,
                        Stretch *o) {
     const uint32_t lo = chunk * kChunk, limit = lo + kChunk;
@@ -161,9 +184,14 @@ AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const uin
         i++;
         if (closing) { closed = true; break; }
     }
-    // merged: one range, 16 codes per load
+    // merged: one range, 16 codes per load.  Below `limit` no bin can close the stretch.
     uint32_t Rm = R[0], Tm = 0, end = i;
     if (!closed && i < n) {
+        const uint32_t interior_end = limit < n ? limit : n;
+        if (i < interior_end) {
+            for_codes_all(res, i, interior_end, [&](uint32_t c) { Tm += step_range(c, rows, &Rm); });
+            i = interior_end;
+        }
         end = n;
         for_codes(res, i, n, [&](uint32_t idx, uint32_t c) {
             const bool closing = idx >= limit && code_is_boundary(c);
@@ -232,7 +260,7 @@ AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, ui
     // local coder in the reference's form, pre-shifted so its digits sit on the global digit grid
     uint32_t low = 0, range = R << (22 - phase);
     uint32_t j = 0, prev = 0;                              // digits produced; the last one, held one step
-    for_codes(res, from, st.end, [&](uint32_t, uint32_t c) {
+    for_codes_all(res, from, st.end, [&](uint32_t c) {
         const int norm = 23 - clz32(range);                // cabac_code.h:37
         const uint32_t q = (range >> (norm + 6)) & 3;      // :39-40
         const uint32_t rt = ((rows[c >> 2] >> (8 * q)) & 0xffu) << norm;   // :40-41, :60
@@ -251,7 +279,6 @@ AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, ui
             low = (low & 0x7fffu) << 16;
             range <<= 16;
         }
-        return false;
     });
     // what is left: the held digit (+ the window's carry bit) and the 31-bit window itself
     if (j > 0) S.add(g0 + j - 1, prev + (low >> 31));
