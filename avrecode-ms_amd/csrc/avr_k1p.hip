@@ -94,89 +94,111 @@ __global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, uint32_t *hist, uint3
     if (k == 1023) run_start[size_t(s) * (nk + 1) + nk] = sc[1023];
 }
 
-// One wave per sort block.  Bins are taken 64 at a time in stream order; the lanes holding the
-// same context find each other with one ballot per key bit, which gives every bin its rank among
-// them (stable), and the first of them advances the context's running position.
+// One workgroup of 4 waves per sort block; wave w takes the w-th quarter of the block.  Bins are
+// taken 64 at a time in stream order; the lanes holding the same context find each other with one
+// ballot per key bit, which gives every bin its rank among them (stable), and the first of them
+// advances the context's running position.  A wave is a serial chain through those running
+// positions, so the block is quartered to shorten it: the quarters are counted first (LDS atomics),
+// each wave starts from the block's local start of the context plus what the quarters before it hold.
 //
 // The block is sorted into LDS first and copied out afterwards: its bins of one context go to
 // consecutive global positions, so the copy-out stores are runs of consecutive bytes, where a
 // direct scatter would be 64 different cache lines per store instruction (measured: the direct
 // form spent 75 % of its wave cycles stalled on issuing those stores).
-__global__ __launch_bounds__(64) void k_k1p_scatter(Plan p, const int32_t *status, const uint32_t *boff,
-                                                    const uint32_t *run_start, uint8_t *sorted, uint32_t *pos,
-                                                    uint32_t key_bits) {
+constexpr uint32_t kQuarter = kSortBlock / 4, kQuarterBatches = kQuarter / 64;
+
+__global__ __launch_bounds__(256) void k_k1p_scatter(Plan p, const int32_t *status, const uint32_t *boff,
+                                                     const uint32_t *run_start, uint8_t *sorted, uint32_t *pos,
+                                                     uint32_t key_bits) {
     // LDS (dynamic, sized by the number of contexts so that more blocks fit a CU):
     extern __shared__ uint32_t scatter_lds[];
     const uint32_t nk = p.n_states, nk_pad = (nk + 63) & ~63u;
-    uint32_t *cnt = scatter_lds;                                 // next local position of each context
-    uint32_t *delta = cnt + nk_pad;                              // global position - local position
+    uint32_t *cnt = scatter_lds;                                 // [4][nk_pad]: next local position, per wave
+    uint32_t *delta = cnt + 4 * nk_pad;                          // global position - local position
     uint16_t *kbuf = reinterpret_cast<uint16_t *>(delta + nk_pad);   // context of every locally sorted bin
     uint8_t *lbuf = reinterpret_cast<uint8_t *>(kbuf + kSortBlock);  // the bins, locally sorted
-    const uint32_t b = blockIdx.x, s = p.blk_slice[b], lane = threadIdx.x;
+    __shared__ uint32_t sh_n_local;
+    const uint32_t b = blockIdx.x, s = p.blk_slice[b], t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (status[s] != AVR_SLICE_OK) return;
-    const bool last_block = b + 1 == p.blk_base[s + 1];
-    const uint32_t *g0 = boff + size_t(b) * nk;
-    const uint32_t *g1 = last_block ? run_start + size_t(s) * (nk + 1) + 1 : g0 + nk;   // where context k stops
-    // local exclusive scan of the block's per-context counts: 16 consecutive contexts per lane
-    uint32_t mine[16], sum = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 16; j++) {
-        const uint32_t k = lane * 16 + j;
-        mine[j] = k < nk ? g1[k] - g0[k] : 0;
-        sum += mine[j];
-    }
-    uint32_t incl = sum;
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
-    }
-    uint32_t run = incl - sum;
-    const uint32_t n_local = __shfl(incl, 63);                   // context bins in this block
-#pragma unroll
-    for (uint32_t j = 0; j < 16; j++) {
-        const uint32_t k = lane * 16 + j;
-        if (k < nk) { cnt[k] = run; delta[k] = g0[k] - run; }
-        run += mine[j];
-    }
-    __syncthreads();
     const uint32_t n = p.n_bins[s], i0 = (b - p.blk_base[s]) * kSortBlock;
     const uint32_t i1 = i0 + kSortBlock < n ? i0 + kSortBlock : n;
     const uint16_t *r = p.recs + p.rec_off[s];
-    uint8_t *so = sorted + p.res_off[s];
-    uint32_t *po = pos + p.res_off[s];
-    const uint64_t lt = (uint64_t(1) << lane) - 1;
-    for (uint32_t base = i0; base < i1; base += 512) {           // 8 batches per trip, loads issued together
-        uint32_t recs8[8];
+    // this wave's records: batch j of the quarter is r[q0 + 64 j + lane]
+    const uint32_t q0 = i0 + w * kQuarter;
+    uint32_t recs[kQuarterBatches];
 #pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            const uint32_t i = base + 64 * j + lane;
-            recs8[j] = i < i1 ? r[i] : uint32_t(AVR_NOP_CABAC);
+    for (uint32_t j = 0; j < kQuarterBatches; j++) {
+        const uint32_t i = q0 + 64 * j + lane;
+        recs[j] = i < i1 ? r[i] : uint32_t(AVR_NOP_CABAC);
+    }
+    for (uint32_t k = t; k < 4 * nk_pad; k += 256) cnt[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < kQuarterBatches; j++) {             // count the quarter
+        const uint32_t sel = (recs[j] >> 1) & 0x7ffu;
+        if (sel < nk) atomicAdd(&cnt[w * nk_pad + sel], 1u);
+    }
+    __syncthreads();
+    if (w == 0) {
+        // local exclusive scan of the block's per-context counts: 16 consecutive contexts per lane
+        const bool last_block = b + 1 == p.blk_base[s + 1];
+        const uint32_t *g0 = boff + size_t(b) * nk;
+        const uint32_t *g1 = last_block ? run_start + size_t(s) * (nk + 1) + 1 : g0 + nk;   // where context k stops
+        uint32_t mine[16], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) {
+            const uint32_t k = lane * 16 + j;
+            mine[j] = k < nk ? g1[k] - g0[k] : 0;
+            sum += mine[j];
         }
+        uint32_t incl = sum;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        uint32_t run = incl - sum;
+        if (lane == 63) sh_n_local = incl;                       // context bins in this block
 #pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            const uint32_t i = base + 64 * j + lane;
-            const uint32_t rec = recs8[j];
-            const uint32_t sel = (rec >> 1) & 0x7ffu;
-            const bool is_ctx = sel < nk;
-            uint64_t mask = __ballot(is_ctx);
-            for (uint32_t bit = 0; bit < key_bits; bit++) {
-                const bool one = (sel >> bit) & 1;
-                const uint64_t m = __ballot(one);
-                mask &= one ? m : ~m;
+        for (uint32_t j = 0; j < 16; j++) {
+            const uint32_t k = lane * 16 + j;
+            if (k < nk) {
+                delta[k] = g0[k] - run;
+                uint32_t at = run;                               // quarter w starts after the quarters before it
+                for (uint32_t q = 0; q < 4; q++) { const uint32_t c = cnt[q * nk_pad + k]; cnt[q * nk_pad + k] = at; at += c; }
             }
-            if (is_ctx) {
-                const uint32_t rank = __popcll(mask & lt);
-                const uint32_t start = cnt[sel];
-                const uint32_t at = start + rank;
-                lbuf[at] = uint8_t(rec & 1);
-                kbuf[at] = uint16_t(sel);
-                po[i] = at + delta[sel];
-                if (rank == 0) cnt[sel] = start + __popcll(mask);
-            }
+            run += mine[j];
         }
     }
     __syncthreads();
-    for (uint32_t j = lane; j < n_local; j += 64) so[j + delta[kbuf[j]]] = lbuf[j];
+    uint32_t *po = pos + p.res_off[s];
+    uint32_t *my_cnt = cnt + w * nk_pad;
+    const uint64_t lt = (uint64_t(1) << lane) - 1;
+#pragma unroll
+    for (uint32_t j = 0; j < kQuarterBatches; j++) {
+        const uint32_t i = q0 + 64 * j + lane;
+        const uint32_t rec = recs[j];
+        const uint32_t sel = (rec >> 1) & 0x7ffu;
+        const bool is_ctx = sel < nk;
+        uint64_t mask = __ballot(is_ctx);
+        for (uint32_t bit = 0; bit < key_bits; bit++) {
+            const bool one = (sel >> bit) & 1;
+            const uint64_t m = __ballot(one);
+            mask &= one ? m : ~m;
+        }
+        if (is_ctx) {
+            const uint32_t rank = __popcll(mask & lt);
+            const uint32_t start = my_cnt[sel];
+            const uint32_t at = start + rank;
+            lbuf[at] = uint8_t(rec & 1);
+            kbuf[at] = uint16_t(sel);
+            po[i] = at + delta[sel];
+            if (rank == 0) my_cnt[sel] = start + __popcll(mask);
+        }
+    }
+    __syncthreads();
+    uint8_t *so = sorted + p.res_off[s];
+    const uint32_t n_local = sh_n_local;
+    for (uint32_t j = t; j < n_local; j += 256) so[j + delta[kbuf[j]]] = lbuf[j];
 }
 
 // ---- A4: state chains over the sorted order.
@@ -587,8 +609,8 @@ static hipError_t launch_resolve(hipStream_t s, const Plan &p, uint32_t n_slices
     if (n_states > 0) {
         hipLaunchKernelGGL(k_k1p_hist, dim3(pl->total_blocks), dim3(256), 0, s, p, status, hist);
         hipLaunchKernelGGL(k_k1p_scan, dim3(n_slices), dim3(1024), 0, s, p, hist, run_start);
-        const uint32_t scatter_lds = 8 * ((n_states + 63) & ~63u) + 3 * kSortBlock;
-        hipLaunchKernelGGL(k_k1p_scatter, dim3(pl->total_blocks), dim3(64), scatter_lds, s, p, status, hist, run_start, sorted,
+        const uint32_t scatter_lds = 20 * ((n_states + 63) & ~63u) + 3 * kSortBlock;
+        hipLaunchKernelGGL(k_k1p_scatter, dim3(pl->total_blocks), dim3(256), scatter_lds, s, p, status, hist, run_start, sorted,
                            pos, key_bits);
         hipLaunchKernelGGL(k_k1p_spec, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
                            sorted, seg);
