@@ -113,6 +113,10 @@ SIGNATURES = {
                                                c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "avr_range_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "avr_context_census_device": (c_int, [c_int, c_void_p, c_void_p, c_uint64, c_void_p]),
+    "avr_context_remap_device": (c_int, [c_int, c_void_p, c_void_p, c_uint64, c_void_p]),
+    "avr_states_permute_device": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,
+                                          c_size_t, c_int]),
     "avr_synth_config_init": (c_int, [POINTER(SynthConfig), c_int, c_uint32, c_uint64]),
     "avr_synth_count_host": (c_int, [POINTER(SynthConfig), c_int, c_size_t, c_void_p]),
     "avr_synth_generate_host": (c_int, [POINTER(SynthConfig), c_int, c_size_t, c_void_p, c_void_p, c_void_p]),

@@ -509,6 +509,32 @@ int avr_range_encode_slices_device(int device, void *stream, const uint16_t *rec
     return AVR_OK;
 }
 
+// ------------------------------------------------------------------ dense context ids
+
+int avr_context_census_device(int device, void *stream, const uint16_t *recs, uint64_t n_records, uint32_t *bitmap) {
+    if ((n_records && !recs) || !bitmap || (n_records & 7)) return fail(AVR_ERR_INVALID, "bad argument (n_records must be a multiple of 8)");
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_context_census(static_cast<hipStream_t>(stream), recs, n_records, bitmap));
+    return AVR_OK;
+}
+
+int avr_context_remap_device(int device, void *stream, uint16_t *recs, uint64_t n_records, const uint16_t *table) {
+    if ((n_records && !recs) || !table || (n_records & 7)) return fail(AVR_ERR_INVALID, "bad argument (n_records must be a multiple of 8)");
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_context_remap(static_cast<hipStream_t>(stream), recs, n_records, table));
+    return AVR_OK;
+}
+
+int avr_states_permute_device(int device, void *stream, const uint8_t *src, size_t n_src, uint8_t *dst, size_t n_dst,
+                              const uint16_t *index, size_t n_index, size_t n_slices, int scatter) {
+    if (n_slices && n_index && (!src || !dst || !index)) return fail(AVR_ERR_INVALID, "null pointer");
+    if (n_src > AVR_MAX_STATES || n_dst > AVR_MAX_STATES || n_index > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "more than %d states", AVR_MAX_STATES);
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_states_permute(static_cast<hipStream_t>(stream), src, uint32_t(n_src), dst, uint32_t(n_dst), index,
+                                       uint32_t(n_index), n_slices, scatter));
+    return AVR_OK;
+}
+
 // ------------------------------------------------------------------ synthetic streams
 
 int avr_synth_config_init(avr_synth_config *cfg, int workload, uint32_t scale_permille, uint64_t first_slice) {

@@ -35,6 +35,10 @@ hipError_t launch_synth_tiles(hipStream_t s, int workload, uint32_t scale, uint6
                               const uint64_t *tile_off, void *tiles, uint8_t *init_states,
                               uint32_t n_states);
 
+hipError_t launch_context_census(hipStream_t s, const uint16_t *recs, uint64_t n, uint32_t *bitmap);
+hipError_t launch_context_remap(hipStream_t s, uint16_t *recs, uint64_t n, const uint16_t *table);
+hipError_t launch_states_permute(hipStream_t s, const uint8_t *src, uint32_t n_src, uint8_t *dst, uint32_t n_dst,
+                                 const uint16_t *index, uint32_t n_index, uint64_t n_slices, int scatter);
 hipError_t launch_compact(hipStream_t s, const uint8_t *out, const uint64_t *out_off, const uint32_t *out_len,
                           const uint64_t *dense_off, uint32_t n_slices, uint8_t *dense);
 

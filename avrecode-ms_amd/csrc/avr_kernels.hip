@@ -303,6 +303,61 @@ __global__ __launch_bounds__(64) void k_pack_tiles(
     if (active && bad) status[slice] = AVR_SLICE_BAD_RECORD;
 }
 
+// ------------------------------------------------------------------ dense context ids
+
+// A slice's contexts are identified by their offset in libavcodec's cabac_state[1024]
+// (recode.cpp:325 keys on the address), but a stream touches far fewer: state bytes cost LDS
+// (64 lanes x n_states per wave), so a batch is renumbered onto the contexts it uses.
+// census: which selectors < 1024 occur in a flat array of CABAC records (tiles or slice-major).
+__global__ __launch_bounds__(256) void k_context_census(const uint16_t *recs, uint64_t n, uint32_t *bitmap) {
+    __shared__ uint32_t bm[32];
+    if (threadIdx.x < 32) bm[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = uint64_t(gridDim.x) * 256 * 8;
+    for (uint64_t i = (uint64_t(blockIdx.x) * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(recs + i);       // n is a multiple of 8 (whole chunks)
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t sel = ((w[j >> 1] >> ((j & 1) * 16)) >> 1) & 0x7ffu;
+            if (sel < 1024) atomicOr(&bm[sel >> 5], 1u << (sel & 31));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && bm[threadIdx.x]) atomicOr(&bitmap[threadIdx.x], bm[threadIdx.x]);
+}
+
+// remap: selector s < 1024 -> table[s] (dense id), other selectors unchanged; in place.
+__global__ __launch_bounds__(256) void k_context_remap(uint16_t *recs, uint64_t n, const uint16_t *table) {
+    __shared__ uint16_t t[1024];
+    for (uint32_t i = threadIdx.x; i < 1024; i += 256) t[i] = table[i];
+    __syncthreads();
+    const uint64_t stride = uint64_t(gridDim.x) * 256 * 8;
+    for (uint64_t i = (uint64_t(blockIdx.x) * 256 + threadIdx.x) * 8; i < n; i += stride) {
+        uint4 v = *reinterpret_cast<uint4 *>(recs + i);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t sh = (j & 1) * 16;
+            const uint32_t rec = (w[j >> 1] >> sh) & 0xffffu, sel = (rec >> 1) & 0x7ffu;
+            const uint32_t out = sel < 1024 ? ((rec & 1) | (uint32_t(t[sel]) << 1)) : rec;
+            w[j >> 1] = (w[j >> 1] & ~(0xffffu << sh)) | (out << sh);
+        }
+        *reinterpret_cast<uint4 *>(recs + i) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// dst[slice][j] = src[slice][index[j]] (gather, n_dst per slice) or dst[slice][index[j]] = src[slice][j] (scatter)
+__global__ __launch_bounds__(256) void k_states_permute(const uint8_t *src, uint32_t n_src, uint8_t *dst, uint32_t n_dst,
+                                                        const uint16_t *index, uint32_t n_index, uint64_t n_slices, int scatter) {
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n_slices * n_index) return;
+    const uint64_t s = i / n_index;
+    const uint32_t j = uint32_t(i % n_index);
+    if (scatter) dst[s * n_dst + index[j]] = src[s * n_src + j];
+    else dst[s * n_dst + j] = src[s * n_src + index[j]];
+}
+
 // ------------------------------------------------------------------ compact: per-slice regions -> dense
 
 // One workgroup per slice; the copy is contiguous on both sides.  dense_off[i+1]-dense_off[i]
@@ -448,6 +503,29 @@ hipError_t launch_pack_tiles(hipStream_t s, int kind, uint32_t n_states, const u
     const dim3 grid((n_slices + 63) / 64), block(64);
     hipLaunchKernelGGL(k_pack_tiles, grid, block, 0, s, kind, n_states, recs, rec_off, n_bins, order, n_slices,
                        tile_off, reinterpret_cast<uint4 *>(tiles), status);
+    return hipGetLastError();
+}
+
+hipError_t launch_context_census(hipStream_t s, const uint16_t *recs, uint64_t n, uint32_t *bitmap) {
+    if (n == 0) return hipSuccess;
+    const uint64_t want = (n / 8 + 255) / 256;
+    hipLaunchKernelGGL(k_context_census, dim3(uint32_t(want < 4096 ? want : 4096)), dim3(256), 0, s, recs, n, bitmap);
+    return hipGetLastError();
+}
+
+hipError_t launch_context_remap(hipStream_t s, uint16_t *recs, uint64_t n, const uint16_t *table) {
+    if (n == 0) return hipSuccess;
+    const uint64_t want = (n / 8 + 255) / 256;
+    hipLaunchKernelGGL(k_context_remap, dim3(uint32_t(want < 8192 ? want : 8192)), dim3(256), 0, s, recs, n, table);
+    return hipGetLastError();
+}
+
+hipError_t launch_states_permute(hipStream_t s, const uint8_t *src, uint32_t n_src, uint8_t *dst, uint32_t n_dst,
+                                 const uint16_t *index, uint32_t n_index, uint64_t n_slices, int scatter) {
+    const uint64_t total = n_slices * n_index;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_states_permute, dim3(uint32_t((total + 255) / 256)), dim3(256), 0, s, src, n_src, dst, n_dst, index,
+                       n_index, n_slices, scatter);
     return hipGetLastError();
 }
 

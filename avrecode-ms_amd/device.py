@@ -140,6 +140,55 @@ class DeviceWorkload:
         encode_tiles(self.kind, self.tiles, self.tile_off, self.n_bins, self.order, self.out, self.out_off,
                      self.out_len, self.status, self.init_states, self.n_states, self.final_states, self.device_index)
 
+    def densify(self):
+        """Renumber the batch onto the contexts it uses (fewer state bytes in LDS -> more waves per CU).
+
+        Records (tiles and, if present, the slice-major copy) are rewritten in place, init_states
+        is gathered to the dense numbering; final states are scattered back by final_states_full().
+        Coded bytes do not change: they depend on (bin, state) sequences only."""
+        import numpy as np
+        import torch
+        if self.kind != KIND_CABAC or getattr(self, "dense_index", None) is not None:
+            return self
+        L = lib()
+        dev = self.n_bins.device
+        sp = _stream_ptr(torch)
+        bitmap = torch.zeros(32, dtype=torch.int32, device=dev)
+        n_tile_recs = self.tiles.numel() // 2
+        _check(L.avr_context_census_device(self.device_index, sp, self.tiles.data_ptr(), n_tile_recs, bitmap.data_ptr()))
+        bits = np.unpackbits(bitmap.cpu().numpy().view(np.uint8), bitorder="little")[:1024]
+        used = np.nonzero(bits)[0].astype(np.uint16)
+        used = used[used < self.n_states] if self.n_states else used
+        table = np.zeros(1024, dtype=np.uint16)
+        table[used] = np.arange(used.size, dtype=np.uint16)
+        d_table = torch.from_numpy(table.view(np.int16)).to(dev)
+        d_index = torch.from_numpy(used.view(np.int16)).to(dev)
+        _check(L.avr_context_remap_device(self.device_index, sp, self.tiles.data_ptr(), n_tile_recs, d_table.data_ptr()))
+        if getattr(self, "rec_flat", None) is not None:
+            _check(L.avr_context_remap_device(self.device_index, sp, self.rec_flat.data_ptr(),
+                                              int(self.rec_off[-1]), d_table.data_ptr()))
+        n_dense = max(int(used.size), 1)
+        dense_init = torch.zeros(self.n_slices * n_dense, dtype=torch.uint8, device=dev)
+        _check(L.avr_states_permute_device(self.device_index, sp, self.init_states.data_ptr(), self.n_states,
+                                           dense_init.data_ptr(), n_dense, d_index.data_ptr(), int(used.size), self.n_slices, 0))
+        torch.cuda.synchronize(dev)
+        self.full_n_states, self.full_init_states = self.n_states, self.init_states
+        self.dense_index, self.init_states, self.n_states = d_index, dense_init, n_dense
+        self.final_states = torch.empty(self.n_slices * n_dense, dtype=torch.uint8, device=dev)
+        self._plan = None
+        return self
+
+    def final_states_full(self):
+        """final states in the original context numbering (contexts never touched keep their initial state)."""
+        import torch
+        if getattr(self, "dense_index", None) is None:
+            return self.final_states
+        full = self.full_init_states.clone()
+        _check(lib().avr_states_permute_device(self.device_index, _stream_ptr(torch), self.final_states.data_ptr(), self.n_states,
+                                               full.data_ptr(), self.full_n_states, self.dense_index.data_ptr(),
+                                               self.dense_index.numel(), self.n_slices, 1))
+        return full
+
     def _slice_major(self):
         """Slice-major records on the device (what the intra-slice parallel path reads)."""
         import torch
@@ -151,6 +200,15 @@ class DeviceWorkload:
             _check(lib().avr_synth_generate_slices_device(
                 self.device_index, _stream_ptr(torch), ctypes.byref(self.cfg), self.kind, self.n_slices,
                 self.rec_off.data_ptr(), self.rec_flat.data_ptr(), None))
+            if getattr(self, "dense_index", None) is not None:      # keep the copy in the batch's numbering
+                import numpy as np
+                table = np.zeros(1024, dtype=np.uint16)
+                idx = self.dense_index.cpu().numpy().view(np.uint16)
+                table[idx] = np.arange(idx.size, dtype=np.uint16)
+                d_table = torch.from_numpy(table.view(np.int16)).to(dev)
+                _check(lib().avr_context_remap_device(self.device_index, _stream_ptr(torch), self.rec_flat.data_ptr(),
+                                                      int(self.rec_off[-1]), d_table.data_ptr()))
+                torch.cuda.synchronize(dev)
         return self.rec_flat, self.rec_off
 
     def _chunk_plan(self):

@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--records", default="bins", choices=["bins", "resolved"],
                     help="bins: (bin, context) records + state tables, the full K1 (default); resolved: time only the "
                          "arithmetic-coding stage of K1p from (bin, state) codes resolved beforehand")
+    ap.add_argument("--full-context-table", action="store_true",
+                    help="keep the contexts as numbered by the stream (default: renumber the batch onto the contexts it uses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL; gloo lets several ranks rehearse on one GPU)")
@@ -176,6 +178,9 @@ def main():
     n_slices = args.slices or DEFAULT_SLICES[args.workload]
     first = shard_first_slice(rank, n_slices)
     w = avr.DeviceWorkload.synth(args.workload, n_slices, kind, local_rank, 1000, first)
+    declared_states = w.n_states
+    if kind == avr.KIND_CABAC and not args.full_context_table:
+        w.densify()
 
     path = args.path
     if path == "auto":        # one lane per slice needs >= ~64 slices per SIMD-wave-slot to fill 256 CUs
@@ -235,7 +240,7 @@ def main():
             "dtype": "u32" if kind == avr.KIND_CABAC else "u64", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[args.workload], "kernel": "K1 cabac_encode" if kind == avr.KIND_CABAC else "K2 range_encode",
                        "slices_per_gpu": n_slices, "bins_per_gpu": w.total_bins, "h264_bytes_per_gpu": out_bytes,
-                       "n_states": w.n_states, "layout": "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
+                       "n_states": w.n_states, "n_states_declared": declared_states, "layout": "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": ("K1p: k_k1p_{hist,scan,scatter,spec,link,chain,gather,b1,b2,zero,c,d} (one step = 13 launches; "

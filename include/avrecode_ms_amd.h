@@ -246,6 +246,22 @@ int avr_range_encode_slices_device(int device, void *stream,
                                    uint8_t *out, const uint64_t *out_off,
                                    uint32_t *out_len, int32_t *status);
 
+/* ------------------------------------------------------------------ dense context ids
+ * A context is identified by the offset of its state byte in libavcodec's cabac_state[1024]
+ * (recode.cpp:325 keys the model on the address), but a stream uses far fewer of them, and K1
+ * keeps 64 lanes x n_states state bytes in LDS per wave: renumbering a batch onto the contexts it
+ * uses raises occupancy.  recs is any flat array of CABAC records on the device (a tile buffer or
+ * a slice-major buffer), n_records a multiple of 8.
+ *   avr_context_census_device   bitmap[32] |= one bit per selector < 1024 that occurs (zero it first)
+ *   avr_context_remap_device    selector s < 1024 -> table[s] in place (table: 1024 x uint16 on the device)
+ *   avr_states_permute_device   gather (scatter = 0): dst[slice][j] = src[slice][index[j]], j < n_index,
+ *                               or scatter back (1): dst[slice][index[j]] = src[slice][j]
+ * The caller builds table / index from the bitmap (128 bytes, host side). */
+int avr_context_census_device(int device, void *stream, const uint16_t *recs, uint64_t n_records, uint32_t *bitmap);
+int avr_context_remap_device(int device, void *stream, uint16_t *recs, uint64_t n_records, const uint16_t *table);
+int avr_states_permute_device(int device, void *stream, const uint8_t *src, size_t n_src, uint8_t *dst, size_t n_dst,
+                              const uint16_t *index, size_t n_index, size_t n_slices, int scatter);
+
 /* ------------------------------------------------------------------ synthetic bin streams
  * Seeded generators for the BASELINE.json configurations; the same code
  * runs on the host (avr_synth_*_host) and on the device so that CPU checks and GPU runs see

@@ -135,3 +135,25 @@ def test_two_stage_form_resolved_codes(avr, oracle):
     wl.encode_resolved(codes2[base:])
     got2, st2 = wl.results()
     assert st2 == [0] and got2[0] == oracle.cabac_encode(((np.arange(n) & 1) | (1024 << 1)).astype(np.uint16), np.zeros(4, np.uint8))[0]
+
+
+@pytest.mark.parametrize("workload,scale,n_slices", [(5, 1000, 2000), (2, 30, 100)])
+def test_dense_context_ids_change_nothing_but_the_numbering(avr, oracle, workload, scale, n_slices):
+    import torch
+    w = avr.DeviceWorkload.synth(workload, n_slices, 0, 0, scale)
+    w.encode()
+    want, _ = w.results()
+    fs = w.final_states.clone()
+    full_n = w.n_states
+    w.densify()
+    assert w.n_states < full_n
+    w.out.zero_(); w.out_len.zero_()
+    w.encode()
+    got, status = w.results()
+    assert not any(status) and got == want
+    assert torch.equal(w.final_states_full(), fs)
+    w.out.zero_(); w.out_len.zero_()
+    w.encode_chunked()
+    got, status = w.results()
+    assert not any(status) and got == want
+    assert torch.equal(w.final_states_full(), fs)
