@@ -125,15 +125,14 @@ AVR_HD void for_codes(const uint8_t *res, uint32_t from, uint32_t n, F &&f) {
 }
 
 // The same for codes that all get the same treatment: g(code) for every code of res[from .. to), no
-// index, no early exit.  Whole 16-byte groups run without per-code bounds tests.
+// index, no early exit.  The bulk is taken 64 bytes per lane per trip (four 16-byte loads issued
+// together): lanes stream from addresses a kilobyte apart, so a 16-byte load drags in a whole
+// cache line per lane and nothing keeps it resident until the lane comes back for the rest.
 template <class G>
 AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g) {
     if (from >= to) return;
-    const uint32_t head_end = ((from + 15) & ~15u) < to ? ((from + 15) & ~15u) : to;
-    for_codes(res, from, head_end, [&](uint32_t, uint32_t c) { g(c); return false; });
-    uint32_t base = head_end;
-    for (; base + 16 <= to; base += 16) {
-        const U4 v = *reinterpret_cast<const U4 *>(res + base);
+    auto four = [&](uint32_t d) { g(d & 0xffu); g((d >> 8) & 0xffu); g((d >> 16) & 0xffu); g(d >> 24); };
+    auto group16 = [&](const U4 &v) {
         uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
@@ -141,8 +140,16 @@ AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g)
         for (uint32_t k = 0; k < 4; k++) {
             const uint32_t d = w0;
             w0 = w1; w1 = w2; w2 = w3;
-            g(d & 0xffu); g((d >> 8) & 0xffu); g((d >> 16) & 0xffu); g(d >> 24);
+            four(d);
         }
+    };
+    const uint32_t head_end = ((from + 63) & ~63u) < to ? ((from + 63) & ~63u) : to;
+    for_codes(res, from, head_end, [&](uint32_t, uint32_t c) { g(c); return false; });
+    uint32_t base = head_end;
+    for (; base + 64 <= to; base += 64) {
+        const U4 *p = reinterpret_cast<const U4 *>(res + base);
+        const U4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        group16(v0); group16(v1); group16(v2); group16(v3);
     }
     if (base < to) for_codes(res, base, to, [&](uint32_t, uint32_t c) { g(c); return false; });
 }

@@ -56,9 +56,16 @@ __global__ __launch_bounds__(256) void k_k1p_hist(Plan p, const int32_t *status,
         const uint32_t n = p.n_bins[s], i0 = (b - p.blk_base[s]) * kSortBlock;
         const uint32_t i1 = i0 + kSortBlock < n ? i0 + kSortBlock : n;
         const uint16_t *r = p.recs + p.rec_off[s];
-        for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) {
-            const uint32_t sel = (r[i] >> 1) & 0x7ffu;
-            if (sel < nk) atomicAdd(&cnt[sel], 1u);
+        // 8 records (one 16-byte chunk) per thread per trip; a slice's padding records are no-ops,
+        // and i0 is a multiple of 8, so whole chunks can be read up to the padded end
+        for (uint32_t i = i0 + threadIdx.x * 8; i < i1; i += 256 * 8) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(r + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t sel = ((w[j >> 1] >> ((j & 1) * 16)) >> 1) & 0x7ffu;
+                if (i + j < i1 && sel < nk) atomicAdd(&cnt[sel], 1u);
+            }
         }
     }
     __syncthreads();
@@ -244,9 +251,7 @@ __device__ __forceinline__ void chain_walk(const uint32_t *next, uint8_t *so, ui
         if (!WRITE) b = chain_next(next, b, bin);
         return code;
     };
-    for (; at < to && (at & 15); at++) { const uint32_t c = one(so[at]); if (WRITE) so[at] = uint8_t(c); }
-    for (; at + 16 <= to; at += 16) {
-        const U4 v = *reinterpret_cast<const U4 *>(so + at);
+    auto group16 = [&](U4 v, uint32_t where) {
         uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -254,8 +259,16 @@ __device__ __forceinline__ void chain_walk(const uint32_t *next, uint8_t *so, ui
             const uint32_t code = one((w[j >> 2] >> sh) & 1u);
             if (WRITE) w[j >> 2] = (w[j >> 2] & ~(0xffu << sh)) | (code << sh);
         }
-        if (WRITE) *reinterpret_cast<U4 *>(so + at) = U4{w[0], w[1], w[2], w[3]};
+        if (WRITE) *reinterpret_cast<U4 *>(so + where) = U4{w[0], w[1], w[2], w[3]};
+    };
+    for (; at < to && (at & 15); at++) { const uint32_t c = one(so[at]); if (WRITE) so[at] = uint8_t(c); }
+    for (; at + 16 <= to && (at & 63); at += 16) group16(*reinterpret_cast<const U4 *>(so + at), at);
+    for (; at + 64 <= to; at += 64) {                    // a whole cache line per lane per trip (see for_codes_all)
+        const U4 *p = reinterpret_cast<const U4 *>(so + at);
+        const U4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        group16(v0, at); group16(v1, at + 16); group16(v2, at + 32); group16(v3, at + 48);
     }
+    for (; at + 16 <= to; at += 16) group16(*reinterpret_cast<const U4 *>(so + at), at);
     for (; at < to; at++) { const uint32_t c = one(so[at]); if (WRITE) so[at] = uint8_t(c); }
 }
 
