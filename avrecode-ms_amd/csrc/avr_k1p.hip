@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_k1p_scatter(Plan p, const int32_t *stat
         }
     }
     __syncthreads();
-    uint32_t *po = pos + p.res_off[s];
+    uint32_t *po = pos + p.res_off[s];                           // position in the slice's sorted order
     uint32_t *my_cnt = cnt + w * nk_pad;
     const uint64_t lt = (uint64_t(1) << lane) - 1;
 #pragma unroll
@@ -385,9 +385,11 @@ __global__ __launch_bounds__(256) void k_k1p_chain(Plan p, uint32_t total_chunks
 }
 
 // One workgroup (256 threads) per chunk of kChunk bins, 4 consecutive bins per thread: the resolved
-// code of every bin in stream order.  Also the one place every record of this path is examined:
-// a selector that is no context of the slice, bypass or terminate, or a bin after
-// put_terminate(1), flags the slice AVR_SLICE_BAD_RECORD.
+// code of every bin in stream order, fetched from the sorted order through the position the scatter
+// kernel left for the bin.  (Measured alternatives that were slower: staging each sort block's runs
+// through LDS first; 16-bit block-local positions plus a per-block offset table.)
+// Also the one place every record of this path is examined: a selector that is no context of the
+// slice, bypass or terminate, or a bin after put_terminate(1), flags the slice AVR_SLICE_BAD_RECORD.
 __global__ __launch_bounds__(256) void k_k1p_gather(Plan p, const uint8_t *sorted, const uint32_t *pos,
                                                     uint8_t *res, int32_t *status) {
     const uint32_t gc = blockIdx.x, s = p.chunk_slice[gc], nk = p.n_states;
