@@ -9,7 +9,7 @@
 //   k_k1p_spec      A4a lane per sorted segment     walk the entered run from the two extreme states
 //   k_k1p_link      A4b lane per sorted segment     true entry state of every segment
 //   k_k1p_chain     A4c lane per sorted segment     state before each bin (cabac_code.h:43-47) -> resolved codes
-//   k_k1p_gather    A5  thread per 4 records        resolved code of every bin, in stream order
+//   k_k1p_replay    A5  lane per sort block         resolved code of every bin, in stream order
 //   k_k1p_b1        B1  lane per chunk              stretch summaries for the 4 entry quarters
 //   k_k1p_b2        B2  lane per slice              chain the summaries: entry range + bit position
 //   k_k1p_zero          workgroup per slice         zero the digit sums that will be used
@@ -47,7 +47,9 @@ struct Plan {                       // device pointers of the caller's plan (avr
 
 // ------------------------------------------------------------------ phase A
 
-__global__ __launch_bounds__(256) void k_k1p_hist(Plan p, const int32_t *status, uint32_t *hist) {
+// Also the one place every record of this path is examined: a selector that is no context of the
+// slice, bypass or terminate, or a bin after put_terminate(1), flags the slice AVR_SLICE_BAD_RECORD.
+__global__ __launch_bounds__(256) void k_k1p_hist(Plan p, int32_t *status, uint32_t *hist) {
     __shared__ uint32_t cnt[AVR_MAX_STATES];
     const uint32_t b = blockIdx.x, s = p.blk_slice[b], nk = p.n_states;
     for (uint32_t k = threadIdx.x; k < nk; k += 256) cnt[k] = 0;
@@ -58,15 +60,22 @@ __global__ __launch_bounds__(256) void k_k1p_hist(Plan p, const int32_t *status,
         const uint16_t *r = p.recs + p.rec_off[s];
         // 8 records (one 16-byte chunk) per thread per trip; a slice's padding records are no-ops,
         // and i0 is a multiple of 8, so whole chunks can be read up to the padded end
+        bool bad = false;
         for (uint32_t i = i0 + threadIdx.x * 8; i < i1; i += 256 * 8) {
             const uint4 v = *reinterpret_cast<const uint4 *>(r + i);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (uint32_t j = 0; j < 8; j++) {
-                const uint32_t sel = ((w[j >> 1] >> ((j & 1) * 16)) >> 1) & 0x7ffu;
-                if (i + j < i1 && sel < nk) atomicAdd(&cnt[sel], 1u);
+                const uint32_t rec = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu, sel = (rec >> 1) & 0x7ffu;
+                if (i + j < i1) {
+                    if (sel < nk) atomicAdd(&cnt[sel], 1u);
+                    else if (sel == AVR_SEL_TERMINATE) bad |= (rec & 1) && i + j + 1 < n;
+                    else bad |= sel != AVR_SEL_BYPASS;
+                    bad |= (rec >> 12) != 0;
+                }
             }
         }
+        if (bad) status[s] = AVR_SLICE_BAD_RECORD;
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < nk; k += 256) hist[size_t(b) * nk + k] = cnt[k];
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, uint32_t *hist, uint3
 constexpr uint32_t kQuarter = kSortBlock / 4, kQuarterBatches = kQuarter / 64;
 
 __global__ __launch_bounds__(256) void k_k1p_scatter(Plan p, const int32_t *status, const uint32_t *boff,
-                                                     const uint32_t *run_start, uint8_t *sorted, uint32_t *pos,
+                                                     const uint32_t *run_start, uint8_t *sorted, uint32_t *qoff,
                                                      uint32_t key_bits) {
     // LDS (dynamic, sized by the number of contexts so that more blocks fit a CU):
     extern __shared__ uint32_t scatter_lds[];
@@ -177,12 +186,16 @@ __global__ __launch_bounds__(256) void k_k1p_scatter(Plan p, const int32_t *stat
         }
     }
     __syncthreads();
-    uint32_t *po = pos + p.res_off[s];                           // position in the slice's sorted order
+    // where every quarter's bins of every context start in the slice's sorted order (for k_k1p_replay)
+    for (uint32_t e = t; e < 4 * nk; e += 256) {
+        const uint32_t q = e / nk, k = e - q * nk;
+        qoff[(size_t(b) * 4 + q) * nk + k] = cnt[q * nk_pad + k] + delta[k];
+    }
+    __syncthreads();
     uint32_t *my_cnt = cnt + w * nk_pad;
     const uint64_t lt = (uint64_t(1) << lane) - 1;
 #pragma unroll
     for (uint32_t j = 0; j < kQuarterBatches; j++) {
-        const uint32_t i = q0 + 64 * j + lane;
         const uint32_t rec = recs[j];
         const uint32_t sel = (rec >> 1) & 0x7ffu;
         const bool is_ctx = sel < nk;
@@ -198,7 +211,6 @@ __global__ __launch_bounds__(256) void k_k1p_scatter(Plan p, const int32_t *stat
             const uint32_t at = start + rank;
             lbuf[at] = uint8_t(rec & 1);
             kbuf[at] = uint16_t(sel);
-            po[i] = at + delta[sel];
             if (rank == 0) my_cnt[sel] = start + __popcll(mask);
         }
     }
@@ -384,39 +396,118 @@ __global__ __launch_bounds__(256) void k_k1p_chain(Plan p, uint32_t total_chunks
     }
 }
 
-// One workgroup (256 threads) per chunk of kChunk bins, 4 consecutive bins per thread: the resolved
-// code of every bin in stream order, fetched from the sorted order through the position the scatter
-// kernel left for the bin.  (Measured alternatives that were slower: staging each sort block's runs
-// through LDS first; 16-bit block-local positions plus a per-block offset table.)
-// Also the one place every record of this path is examined: a selector that is no context of the
-// slice, bypass or terminate, or a bin after put_terminate(1), flags the slice AVR_SLICE_BAD_RECORD.
-__global__ __launch_bounds__(256) void k_k1p_gather(Plan p, const uint8_t *sorted, const uint32_t *pos,
-                                                    uint8_t *res, int32_t *status) {
-    const uint32_t gc = blockIdx.x, s = p.chunk_slice[gc], nk = p.n_states;
-    if (status[s] != AVR_SLICE_OK) return;
-    const uint32_t n = p.n_bins[s];
-    const uint32_t i = (gc - p.chunk_base[s]) * kChunk + threadIdx.x * 4;
-    if (i >= ((n + 15) & ~15u)) return;
-    const uint16_t *r = p.recs + p.rec_off[s];
-    const uint8_t *so = sorted + p.res_off[s];
-    const uint32_t *po = pos + p.res_off[s];
-    uint32_t codes = 0;
-    bool bad = false;
-#pragma unroll
-    for (uint32_t j = 0; j < 4; j++) {
-        uint32_t code = kCodePad;
-        if (i + j < n) {
-            const uint32_t rec = r[i + j], sel = (rec >> 1) & 0x7ffu, bin = rec & 1;
-            if (sel < nk) code = so[po[i + j]];
-            else if (sel == AVR_SEL_BYPASS) code = kCodeBypass | bin;
-            else if (sel == AVR_SEL_TERMINATE) { code = code_terminate(bin); bad |= bin && i + j + 1 < n; }
-            else bad = true;
-            bad |= (rec >> 12) != 0;
+// A5: one lane per chunk (a quarter of a sort block), its records in stream order.  After the chains
+// the resolved code at sorted position qoff[chunk][k] holds the state of context k when the chunk is
+// entered, so a lane loads those states (one byte per context, in LDS, laid out (k, lane) like
+// k_cabac_encode's) and simply plays the chunk's bins: state before the bin -> resolved code,
+// cabac_code.h:43-47 -> next state.  Everything it touches in HBM is read or written once, in order:
+// records in, codes out.  (The form this replaced fetched every bin's code back from the sorted
+// order through a 32-bit position the scatter kernel had stored per bin: 8 more bytes of traffic per
+// bin and a gather of 64 cache lines per load; 0.97 ms on config 2.)
+//
+// The step is branch-free.  Bypass, terminate and padding records go through pseudo contexts nk+1..
+// whose pseudo states 128.. never move, and one LDS table gives, per state, both successors and
+// both resolved codes:  T[st] = next if MPS | next if LPS << 8 | code(bin 0) << 16 | code(bin 1) << 24.
+constexpr uint32_t kStBypass = 128, kStTerminate = 129, kStPad = 130, kStNone = 131, kReplayTable = 192;
+
+__global__ __launch_bounds__(64) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *qoff,
+                                                   const uint8_t *sorted, const uint8_t *init_states, uint8_t *res,
+                                                   const int32_t *status) {
+    extern __shared__ uint32_t replay_lds[];                     // T[kReplayTable], then state dwords [(nk+8)/4][64]
+    uint32_t *T = replay_lds;
+    const uint32_t lane = threadIdx.x, nk = p.n_states;
+    uint8_t *stb = reinterpret_cast<uint8_t *>(replay_lds + kReplayTable) + lane * 4;
+    for (uint32_t st = lane; st < kReplayTable; st += 64) {
+        uint32_t e;
+        if (st < 128) e = d_tables.packed[st][1] | code_context(st, 0) << 16 | code_context(st, 1) << 24;
+        else {
+            const uint32_t c0 = st == kStBypass ? kCodeBypass : st == kStTerminate ? code_terminate(0) : kCodePad;
+            const uint32_t c1 = st == kStBypass ? kCodeBypass | 1 : st == kStTerminate ? code_terminate(1) : kCodePad;
+            e = st | st << 8 | c0 << 16 | c1 << 24;
         }
-        codes |= code << (8 * j);
+        T[st] = e;
     }
-    *reinterpret_cast<uint32_t *>(res + p.res_off[s] + i) = codes;
-    if (bad) status[s] = AVR_SLICE_BAD_RECORD;
+    __syncthreads();
+    const uint32_t gc = blockIdx.x * 64 + lane;
+    if (gc >= total_chunks) return;
+    const uint32_t s = p.chunk_slice[gc];
+    if (status[s] != AVR_SLICE_OK) return;
+    const uint32_t c = gc - p.chunk_base[s];
+    const uint32_t n = p.n_bins[s], i0 = c * kChunk;
+    const uint32_t i1 = i0 + kChunk < n ? i0 + kChunk : n;
+    if (i0 >= n) return;
+    {
+        // chunk c is quarter c & 3 of the slice's sort block c >> 2.  A context without a bin from here
+        // on gets whatever lies at the end of its run: it is never looked at.
+        const uint8_t *so = sorted + p.res_off[s];
+        const uint32_t *bo = qoff + (size_t(p.blk_base[s]) * 4 + c) * nk;
+        const uint8_t *init = init_states + size_t(s) * nk;
+        for (uint32_t k0 = 0; k0 < nk; k0 += 4) {
+            uint32_t at[4], in[4], cd[4], word = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t k = k0 + j < nk ? k0 + j : nk - 1;
+                at[j] = bo[k];
+                in[j] = init[k];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) cd[j] = so[at[j]];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) word |= (cd[j] < 252 ? cd[j] >> 1 : in[j] & 127u) << (8 * j);   // pStateIdx 63 never moves
+            *reinterpret_cast<uint32_t *>(stb + k0 * 64) = word;
+        }
+        const uint32_t pseudo[5] = {kStNone, kStBypass, kStTerminate, kStPad, kStNone};
+#pragma unroll
+        for (uint32_t j = 0; j < 5; j++) stb[((nk + j) >> 2) * 256 + ((nk + j) & 3)] = uint8_t(pseudo[j]);
+    }
+    const uint16_t *r = p.recs + p.rec_off[s];
+    uint8_t *ro = res + p.res_off[s];
+    // 8 records (16 bytes) -> 8 codes
+    auto eight = [&](const U4 &v, uint32_t &c0, uint32_t &c1) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t cc[2] = {0, 0};
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t rec = w[j >> 1] >> ((j & 1) * 16);
+            const uint32_t sel = (rec >> 1) & 0x7ffu, bin = rec & 1;
+            // contexts keep their number; 1024 (bypass), 1025 (terminate), 1026 (no-op) -> nk+1, nk+2, nk+3
+            const uint32_t over = (sel < 1023u ? 1023u : sel > 1027u ? 1027u : sel) - 1023u;
+            const uint32_t kk = (sel < nk ? sel : nk) + over;
+            uint8_t *sp = stb + ((kk & ~3u) << 6) + (kk & 3);
+            const uint32_t st = *sp;
+            const uint32_t e = T[st];
+            *sp = uint8_t(e >> (8 * ((bin ^ st) & 1)));
+            cc[j >> 2] |= ((e >> (16 + 8 * bin)) & 0xffu) << (8 * (j & 3));
+        }
+        c0 = cc[0]; c1 = cc[1];
+    };
+    // a slice's records are padded with no-ops to a multiple of 8, its codes to a multiple of 16
+    uint32_t i = i0;
+    U4 v0, v1, v2, v3;
+    if (i + 32 <= i1) {
+        const U4 *q = reinterpret_cast<const U4 *>(r + i);
+        v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3];
+    }
+    for (; i + 32 <= i1; i += 32) {                              // a cache line of records per trip, the next one in flight
+        U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
+        if (i + 64 <= i1) {
+            const U4 *q = reinterpret_cast<const U4 *>(r + i + 32);
+            n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
+        }
+        U4 a, b;
+        eight(v0, a.x, a.y); eight(v1, a.z, a.w); eight(v2, b.x, b.y); eight(v3, b.z, b.w);
+        *reinterpret_cast<U4 *>(ro + i) = a;
+        *reinterpret_cast<U4 *>(ro + i + 16) = b;
+        v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+    }
+    for (; i < i1; i += 16) {
+        const U4 *q = reinterpret_cast<const U4 *>(r + i);
+        const U4 nop{AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2};
+        const U4 t0 = q[0], t1 = i + 8 < i1 ? q[1] : nop;
+        U4 a;
+        eight(t0, a.x, a.y); eight(t1, a.z, a.w);
+        *reinterpret_cast<U4 *>(ro + i) = a;
+    }
 }
 
 // ------------------------------------------------------------------ phases B1, B2, C
@@ -599,34 +690,26 @@ namespace {
 inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 }
 
-size_t k1p_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl) {
-    return size_t(2 * up256(pl->res_total + 32) + up256(4 * (pl->res_total + 32)) +
-                  up256(uint64_t(pl->total_blocks) * n_states * 4 + 16) + up256(n_slices * uint64_t(n_states + 1) * 4 + 16) +
-                  up256(uint64_t(pl->total_chunks) * sizeof(Seg)) + up256(uint64_t(pl->total_chunks) + 16) +
-                  up256(uint64_t(pl->total_chunks) * sizeof(Stretch)) + up256(uint64_t(pl->total_chunks) * sizeof(Entry)) +
-                  up256(n_slices * sizeof(SliceTotals)) + up256(pl->dig_total * 4 + 16));
-}
-
 // Phase A: records + initial states -> resolved codes `res` (slice i at res + res_off[i]).
-// `w` is workspace for the sort (sorted bins, positions, histograms, run starts, segments).
+// `w` is workspace for the sort (sorted bins, histograms, run starts, segments).
 static hipError_t launch_resolve(hipStream_t s, const Plan &p, uint32_t n_slices, const uint8_t *init_states,
                                  const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, int32_t *status, uint8_t *final_states) {
     const uint32_t n_states = p.n_states;
     uint8_t *sorted = w;                                     w += up256(pl->res_total + 32);
-    uint32_t *pos = reinterpret_cast<uint32_t *>(w);         w += up256(4 * (pl->res_total + 32));
     uint32_t *hist = reinterpret_cast<uint32_t *>(w);        w += up256(uint64_t(pl->total_blocks) * n_states * 4 + 16);
     uint32_t *run_start = reinterpret_cast<uint32_t *>(w);   w += up256(n_slices * uint64_t(n_states + 1) * 4 + 16);
     Seg *seg = reinterpret_cast<Seg *>(w);                   w += up256(uint64_t(pl->total_chunks) * sizeof(Seg));
-    uint8_t *entry = w;
+    uint8_t *entry = w;                                      w += up256(uint64_t(pl->total_chunks) + 16);
+    uint32_t *qoff = reinterpret_cast<uint32_t *>(w);
     uint32_t key_bits = 0;
     while ((1u << key_bits) < n_states) key_bits++;
     const uint32_t chunk_blocks = (pl->total_chunks + 255) / 256;
+    hipLaunchKernelGGL(k_k1p_hist, dim3(pl->total_blocks), dim3(256), 0, s, p, status, hist);
     if (n_states > 0) {
-        hipLaunchKernelGGL(k_k1p_hist, dim3(pl->total_blocks), dim3(256), 0, s, p, status, hist);
         hipLaunchKernelGGL(k_k1p_scan, dim3(n_slices), dim3(1024), 0, s, p, hist, run_start);
         const uint32_t scatter_lds = 20 * ((n_states + 63) & ~63u) + 3 * kSortBlock;
         hipLaunchKernelGGL(k_k1p_scatter, dim3(pl->total_blocks), dim3(256), scatter_lds, s, p, status, hist, run_start, sorted,
-                           pos, key_bits);
+                           qoff, key_bits);
         hipLaunchKernelGGL(k_k1p_spec, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
                            sorted, seg);
         hipLaunchKernelGGL(k_k1p_link, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
@@ -634,7 +717,9 @@ static hipError_t launch_resolve(hipStream_t s, const Plan &p, uint32_t n_slices
         hipLaunchKernelGGL(k_k1p_chain, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
                            sorted, seg, entry, final_states);
     }
-    hipLaunchKernelGGL(k_k1p_gather, dim3(pl->total_chunks), dim3(256), 0, s, p, sorted, pos, res, status);
+    const uint32_t replay_lds = kReplayTable * 4 + ((n_states + 8) / 4) * 256;
+    hipLaunchKernelGGL(k_k1p_replay, dim3((pl->total_chunks + 63) / 64), dim3(64), replay_lds, s, p, pl->total_chunks, qoff,
+                       sorted, init_states, res, status);
     return hipGetLastError();
 }
 
@@ -656,9 +741,14 @@ static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, c
 }
 
 static inline uint64_t resolve_ws_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl) {
-    return up256(pl->res_total + 32) + up256(4 * (pl->res_total + 32)) + up256(uint64_t(pl->total_blocks) * n_states * 4 + 16) +
+    return up256(pl->res_total + 32) + up256(uint64_t(pl->total_blocks) * n_states * 4 + 16) +
            up256(n_slices * uint64_t(n_states + 1) * 4 + 16) + up256(uint64_t(pl->total_chunks) * sizeof(Seg)) +
-           up256(uint64_t(pl->total_chunks) + 16);
+           up256(uint64_t(pl->total_chunks) + 16) + up256(uint64_t(pl->total_blocks) * n_states * 16 + 16);
+}
+
+size_t k1p_code_workspace_bytes(size_t n_slices, const avr_chunk_plan *pl);
+size_t k1p_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl) {
+    return size_t(up256(pl->res_total + 32) + resolve_ws_bytes(n_slices, n_states, pl)) + k1p_code_workspace_bytes(n_slices, pl);
 }
 
 hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
