@@ -5,10 +5,8 @@
 // throws (std::runtime_error / std::invalid_argument), and the C wrappers in avr_host_c.cpp turn
 // them into return codes.
 //
-//   h264_model           recode.cpp:625-1066, the arithmetic every bin passes through:
-//                        estimator {pos,neg} (:1064), probability_for_model_key (:823-827),
-//                        update_state_for_model_key (:1037-1052), get_model_key for the coding
-//                        types that do not need the frame store (:685-690), reset (:669-672)
+//   h264_model           recode.cpp:625-1066, in avr_model.h: estimators, model keys, frame store,
+//                        the nonzero-count side channel of the significance maps
 //   range_decoder        recoded_code::decoder, arithmetic_code.h:209-298 (K3: stays on the CPU,
 //                        it is interleaved with libavcodec's syntax parsing)
 //   cabac_bin_decoder    the CABAC decoding engine of H.264 9.3.3.2, the part of libavcodec the
@@ -32,75 +30,11 @@
 #include <vector>
 
 #include "../avr_tables.h"
+#include "avr_model.h"
 #include "../../../include/avrecode_ms_amd.h"
 
 namespace avr {
 namespace host {
-
-// Coding types the model distinguishes (the values recode.cpp uses, :685-691, :809; the full
-// list lives in the absent libavcodec/coding_hooks.h).
-enum CodingType {
-    PIP_UNKNOWN = 0,
-    PIP_UNREACHABLE,
-    PIP_RESIDUALS,
-    PIP_SIGNIFICANCE_MAP,
-    PIP_SIGNIFICANCE_EOB,
-    PIP_SIGNIFICANCE_NZ,
-};
-
-// Dense stand-ins for the addresses the reference keys its model on (recode.cpp:325, :1056):
-// a slice's context i is key i, bypass and terminate have keys of their own.
-constexpr int kKeyBypass = AVR_SEL_BYPASS, kKeyTerminate = AVR_SEL_TERMINATE;
-
-typedef std::tuple<int, int, int> model_key;           // (context id, int, int), recode.cpp:325
-
-class h264_model {
-  public:
-    CodingType coding_type = PIP_UNKNOWN;              // recode.cpp:627
-    struct estimator { int pos = 1, neg = 1; };        // recode.cpp:1064
-
-    // recode.cpp:669-672: reset() forgets nothing that was learned
-    void reset() {}
-
-    // recode.cpp:683-690; the significance-map keys (:691-816) need the frame store
-    model_key get_model_key(int context) const {
-        switch (coding_type) {
-            case PIP_SIGNIFICANCE_NZ:
-            case PIP_UNKNOWN:
-            case PIP_UNREACHABLE:
-            case PIP_RESIDUALS:
-                return model_key(context, 0, 0);
-            default:
-                throw std::runtime_error("h264_model: significance-map model keys are not part of this build");
-        }
-    }
-    estimator *lookup(const model_key &key) {
-        if (std::get<1>(key) == 0 && std::get<2>(key) == 0 && unsigned(std::get<0>(key)) < 1026) return &flat_[std::get<0>(key)];
-        return &estimators_[key];
-    }
-    uint64_t probability_for_model_key(uint64_t range, const model_key &key) {          // recode.cpp:823-827
-        const estimator *e = lookup(key);
-        const int total = e->pos + e->neg;
-        return (range / uint64_t(total)) * uint64_t(e->pos);
-    }
-    uint64_t probability_for_state(uint64_t range, int context) {                      // recode.cpp:828-830
-        return probability_for_model_key(range, get_model_key(context));
-    }
-    void update_state_for_model_key(int symbol, const model_key &key) {                 // recode.cpp:1037-1054
-        estimator *e = lookup(key);
-        if (symbol) e->pos++; else e->neg++;
-        if ((coding_type != PIP_SIGNIFICANCE_MAP && e->pos + e->neg > 0x60) ||
-            (coding_type == PIP_SIGNIFICANCE_MAP && e->pos + e->neg > 0x50)) {
-            e->pos = (e->pos + 1) / 2;
-            e->neg = (e->neg + 1) / 2;
-        }
-    }
-    void update_state(int symbol, int context) { update_state_for_model_key(symbol, get_model_key(context)); }   // :1034-1036
-
-  private:
-    estimator flat_[1026];
-    std::map<model_key, estimator> estimators_;        // recode.cpp:1065
-};
 
 // ---------------------------------------------------------------------------------------------
 // recoded_code::decoder<const char*, uint8_t>  (arithmetic_code<uint64_t, uint8_t>, recode.cpp:322-323)
@@ -194,23 +128,59 @@ class cabac_bin_decoder {
 class compress_recorder {
   public:
     explicit compress_recorder(h264_model *model) : model_(model) { model_->reset(); }  // recode.cpp:1162-1163
-    // h264_symbol::execute (recode.cpp:1075-1103) with the coder call replaced by a record
+
+    // compressor::cabac_decoder::execute_symbol (recode.cpp:1167-1180): the bins of a significance
+    // map are held back until the block's nonzero count is known (QUEUE_MODE), everything else is
+    // coded where it stands
     void execute_symbol(int symbol, int context) {
         if (finished_) throw std::runtime_error("compress_recorder: bin after the end of the slice");
-        if (model_->coding_type != PIP_SIGNIFICANCE_EOB) {                              // :1080
-            const model_key key = model_->get_model_key(context);
-            const h264_model::estimator *e = model_->lookup(key);
-            recs_.push_back(uint16_t((symbol & 1) | (e->pos << 1) | (e->neg << 8)));   // :823-827 inputs
+        if (queueing_ == PIP_SIGNIFICANCE_MAP || queueing_ == PIP_SIGNIFICANCE_EOB || !queue_.empty()) {
+            queue_.push_back({symbol, context});
+            model_->update_state_tracking(symbol);
+        } else {
+            execute(symbol, context);
         }
-        model_->update_state(symbol, context);                                          // :1094
-        if (context == kKeyTerminate && symbol) finished_ = true;                       // :1099-1102
+    }
+    void begin_coding_type(CodingType ct, int zigzag_index, int param0, int param1) {   // :1201-1209
+        const bool begin_queue = model_->begin_coding_type(ct, zigzag_index, param0, param1);
+        if (begin_queue && (ct == PIP_SIGNIFICANCE_MAP || ct == PIP_SIGNIFICANCE_EOB)) {
+            if (queueing_ != PIP_UNKNOWN || !queue_.empty()) throw std::runtime_error("compress_recorder: nested queues are not supported");   // :1243-1245
+            queueing_ = ct;
+        }
+    }
+    void end_coding_type(CodingType ct) {                                               // :1210-1236
+        model_->end_coding_type(ct);
+        if (ct != PIP_SIGNIFICANCE_MAP && ct != PIP_SIGNIFICANCE_EOB) return;
+        if (queueing_ == PIP_UNKNOWN) throw std::runtime_error("compress_recorder: end of a coding type that was not begun");         // :1250
+        queueing_ = PIP_UNKNOWN;
+        model_->finished_queueing(ct, [&](const model_key &key, int *symbol) {          // the nonzero count first ...
+            record(*symbol, key);
+            model_->update_state_for_model_key(*symbol, key);
+        });
+        model_->reset_mb_significance_state_tracking();                                 // ... then the map (:1254-1265)
+        for (const queued &q : queue_) execute(q.symbol, q.context);
+        queue_.clear();
+        model_->coding_type = PIP_UNKNOWN;
     }
     bool finished() const { return finished_; }
     const std::vector<uint16_t> &records() const { return recs_; }
 
   private:
+    // h264_symbol::execute (recode.cpp:1075-1103) with the coder call replaced by a record
+    void execute(int symbol, int context) {
+        if (model_->coding_type != PIP_SIGNIFICANCE_EOB) record(symbol, model_->get_model_key(context));   // :1080
+        model_->update_state(symbol, context);                                          // :1094
+        if (context == kKeyTerminate && symbol) finished_ = true;                       // :1099-1102
+    }
+    void record(int symbol, const model_key &key) {                                     // :823-827 inputs
+        const h264_model::estimator *e = model_->lookup(key);
+        recs_.push_back(uint16_t((symbol & 1) | (e->pos << 1) | (e->neg << 8)));
+    }
+    struct queued { int symbol, context; };
     h264_model *model_;
     std::vector<uint16_t> recs_;
+    std::vector<queued> queue_;                                                          // symbol_buffer, :1273
+    CodingType queueing_ = PIP_UNKNOWN;
     bool finished_ = false;
 };
 
@@ -227,9 +197,9 @@ class decompress_recorder {
     }
     int get(uint8_t *state) {                                                           // :1442-1456
         const int context = context_of(state);
-        if (model_->coding_type == PIP_SIGNIFICANCE_EOB)
-            throw std::runtime_error("decompress_recorder: significance-map model keys are not part of this build");
-        const int symbol = decoder_.get(model_->probability_for_state(decoder_.range(), context));
+        int symbol;
+        if (model_->coding_type == PIP_SIGNIFICANCE_EOB) symbol = std::get<1>(model_->get_model_key(context));   // not coded: implied by the count
+        else symbol = decoder_.get(model_->probability_for_state(decoder_.range(), context));
         if (!seen_[context]) { seen_[context] = 1; init_states_[context] = *state; n_states_ = std::max(n_states_, context + 1); }
         recs_.push_back(uint16_t(symbol | (context << 1)));                             // cabac_encoder.put, deferred
         const CabacTables &t = cabac_bin_decoder::tables();                             // cabac_code.h:43-47
@@ -250,6 +220,15 @@ class decompress_recorder {
         if (symbol) finished_ = true;
         return symbol;
     }
+    void begin_coding_type(CodingType ct, int zigzag_index, int param0, int param1) {   // :1483-1499
+        const bool begin_queue = model_->begin_coding_type(ct, zigzag_index, param0, param1);
+        if (begin_queue && ct)
+            model_->finished_queueing(ct, [&](const model_key &key, int *symbol) {      // the block's nonzero count comes first
+                *symbol = decoder_.get(model_->probability_for_model_key(decoder_.range(), key));
+                model_->update_state_for_model_key(*symbol, key);
+            });
+    }
+    void end_coding_type(CodingType ct) { model_->end_coding_type(ct); }                // :1500-1505
     bool finished() const { return finished_; }
     const std::vector<uint16_t> &records() const { return recs_; }
     const uint8_t *init_states() const { return init_states_; }   // *state as it was at each context's first bin

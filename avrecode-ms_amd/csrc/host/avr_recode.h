@@ -76,13 +76,43 @@ struct hook_adapter {                                    // av_decoder<Driver>'s
         h.cabac.skip_bytes = [](void *, int) -> const uint8_t * {
             throw std::runtime_error("Not implemented: CABAC decoder doesn't use skip_bytes.");     // :168-170
         };
-        h.model.frame_spec = [](void *, int, int, int) {};           // frame store: out of scope
-        h.model.mb_xy = [](void *, int, int) {};
-        h.model.begin_sub_mb = [](void *, int, int, int, int, int) {};
-        h.model.end_sub_mb = [](void *, int, int, int, int, int) {};
-        h.model.begin_coding_type = [](void *, int, int, int, int) {};   // "Not called" (recode.cpp:204, 210)
-        h.model.end_coding_type = [](void *, int) {};
+        h.model.frame_spec = [](void *o, int frame_num, int mb_width, int mb_height) {                  // :173-176
+            static_cast<Driver *>(o)->get_model()->update_frame_spec(frame_num, mb_width, mb_height);
+        };
+        h.model.mb_xy = [](void *o, int x, int y) {                                                     // :177-181
+            h264_model *m = static_cast<Driver *>(o)->get_model();
+            m->mb_coord.mb_x = x;
+            m->mb_coord.mb_y = y;
+        };
+        h.model.begin_sub_mb = [](void *o, int cat, int scan8index, int max_coeff, int is_dc, int chroma422) {   // :182-189
+            h264_model *m = static_cast<Driver *>(o)->get_model();
+            m->sub_mb_cat = cat;
+            m->mb_coord.scan8_index = scan8index;
+            m->sub_mb_size = max_coeff;
+            m->sub_mb_is_dc = is_dc;
+            m->sub_mb_chroma422 = chroma422;
+        };
+        h.model.end_sub_mb = [](void *o, int cat, int scan8index, int max_coeff, int is_dc, int chroma422) {     // :190-202
+            h264_model *m = static_cast<Driver *>(o)->get_model();
+            if (m->sub_mb_cat != cat || m->mb_coord.scan8_index != scan8index || m->sub_mb_size != max_coeff ||
+                m->sub_mb_is_dc != is_dc || m->sub_mb_chroma422 != chroma422)
+                throw std::runtime_error("end_sub_mb does not match begin_sub_mb");      // asserts in the reference
+            m->sub_mb_cat = -1;
+            m->mb_coord.scan8_index = -1;
+            m->sub_mb_size = -1;
+            m->sub_mb_is_dc = 0;
+            m->sub_mb_chroma422 = 0;
+        };
+        // the coding-type hooks go to the one live CABAC decoder (:203-215)
+        h.model.begin_coding_type = [](void *o, int ct, int zigzag_index, int param0, int param1) {
+            only_decoder(static_cast<Driver *>(o))->begin_coding_type(CodingType(ct), zigzag_index, param0, param1);
+        };
+        h.model.end_coding_type = [](void *o, int ct) { only_decoder(static_cast<Driver *>(o))->end_coding_type(CodingType(ct)); };
         return h;
+    }
+    static typename Driver::cabac_decoder *only_decoder(Driver *d) {
+        if (d->cabac_contexts.size() != 1) throw std::runtime_error("coding-type hook with " + std::to_string(d->cabac_contexts.size()) + " live CABAC decoders");   // :206, :212
+        return d->cabac_contexts.begin()->second.get();
     }
 };
 
@@ -140,6 +170,10 @@ class compressor {                                       // recode.cpp:1109-1316
             recorder_->execute_symbol(symbol, kKeyTerminate);
             return symbol;
         }
+        void begin_coding_type(CodingType ct, int zigzag_index, int param0, int param1) {   // :1201-1209
+            if (recorder_) recorder_->begin_coding_type(ct, zigzag_index, param0, param1);
+        }
+        void end_coding_type(CodingType ct) { if (recorder_) recorder_->end_coding_type(ct); }   // :1210-1236
 
       private:
         compressor *c_;
@@ -152,6 +186,7 @@ class compressor {                                       // recode.cpp:1109-1316
     // the decoder's cabac_state[] for the slices to come (stands for the address arithmetic on
     // libavcodec's H264SliceContext that a real integration does)
     void set_state_base(const uint8_t *base) { state_base_ = base; }
+    h264_model *get_model() { return &model_; }          // :1276-1278
     std::map<void *, std::unique_ptr<cabac_decoder>> cabac_contexts;     // :236
 
   private:
@@ -304,6 +339,10 @@ class decompressor {                                     // recode.cpp:1319-1598
         int get(uint8_t *state) { return recorder_->get(state); }
         int get_bypass() { return recorder_->get_bypass(); }
         int get_terminate() { return recorder_->get_terminate(); }
+        void begin_coding_type(CodingType ct, int zigzag_index, int param0, int param1) {   // :1483-1499
+            if (recorder_) recorder_->begin_coding_type(ct, zigzag_index, param0, param1);
+        }
+        void end_coding_type(CodingType ct) { if (recorder_) recorder_->end_coding_type(ct); }   // :1500-1505
 
       private:
         decompressor *d_;
@@ -312,6 +351,7 @@ class decompressor {                                     // recode.cpp:1319-1598
     };
 
     void set_state_base(const uint8_t *base) { state_base_ = base; }
+    h264_model *get_model() { return &model_; }          // :1528-1530
     std::map<void *, std::unique_ptr<cabac_decoder>> cabac_contexts;
 
   private:

@@ -2,7 +2,10 @@
 // that pytest can exercise it, and the recorded-slice feeder that plays libavcodec's part in the
 // roundtrip test (the reference's FFmpeg fork is not available offline).  Links libavrecode_hip.so.
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -59,6 +62,171 @@ struct slice_feeder : stream_decoder {
     }
 };
 
+// ---- a decoder that knows the residual-block syntax (stands for libavcodec's decode_cabac_residual
+// with the model hooks of the reference's fork): per block coded_block_flag, then under
+// PIP_SIGNIFICANCE_MAP the significant_coeff_flag / last_significant_coeff_flag bins in coding order,
+// then one context bin and one bypass bin per nonzero coefficient; per macroblock two context bins
+// up front and end_of_slice (terminate) at the end.  It parses by the bins the hooks RETURN, as a
+// real decoder does, so it works in both directions.
+struct block_desc { int32_t mb_x, mb_y, cat, scan8, max_coeff, is_dc, chroma422; };
+
+inline int ctx_cbf(int cat) { return 85 + cat; }
+inline int ctx_sig(int cat, int i) { return 200 + (cat % 5) * 16 + std::min(i, 15); }
+inline int ctx_last(int cat, int i) { return 300 + (cat % 5) * 16 + std::min(i, 15); }
+inline int ctx_abs(int cat) { return 400 + cat % 5; }
+
+struct syntax_walker {
+    hooks *h; void *dec; uint8_t *cabac_state;
+    std::vector<uint8_t> bins;                            // every bin the hooks returned, in order
+    int get(int ctx) { const int b = h->cabac.get(dec, &cabac_state[ctx]); bins.push_back(uint8_t(b)); return b; }
+    int bypass() { const int b = h->cabac.get_bypass(dec); bins.push_back(uint8_t(b)); return b; }
+    int terminate() { const int b = h->cabac.get_terminate(dec); bins.push_back(uint8_t(b)); return b; }
+
+    void block(const block_desc &b) {
+        h->model.begin_sub_mb(h->opaque, b.cat, b.scan8, b.max_coeff, b.is_dc, b.chroma422);
+        if (get(ctx_cbf(b.cat))) {
+            h->model.begin_coding_type(h->opaque, PIP_SIGNIFICANCE_MAP, 0, 0, 0);
+            int count = 0, i = 0;
+            for (; i < b.max_coeff - 1; i++)
+                if (get(ctx_sig(b.cat, i))) { count++; if (get(ctx_last(b.cat, i))) break; }
+            if (i == b.max_coeff - 1) count++;            // no last flag seen: the final coefficient is significant
+            h->model.end_coding_type(h->opaque, PIP_SIGNIFICANCE_MAP);
+            for (int k = 0; k < count; k++) { get(ctx_abs(b.cat)); bypass(); }
+        }
+        h->model.end_sub_mb(h->opaque, b.cat, b.scan8, b.max_coeff, b.is_dc, b.chroma422);
+    }
+    // one slice: frame_spec, then the macroblocks of `blocks` (grouped by consecutive equal mb_x, mb_y)
+    void slice(int frame_num, int mb_w, int mb_h, const block_desc *blocks, size_t n) {
+        h->model.frame_spec(h->opaque, frame_num, mb_w, mb_h);
+        size_t i = 0;
+        while (i < n) {
+            const int x = blocks[i].mb_x, y = blocks[i].mb_y;
+            h->model.mb_xy(h->opaque, x, y);
+            get(3); get(4);                               // "mb_type"
+            for (; i < n && blocks[i].mb_x == x && blocks[i].mb_y == y; i++) block(blocks[i]);
+            if (terminate() != (i == n)) throw std::runtime_error("syntax_walker: end_of_slice out of place");
+        }
+    }
+};
+
+// The same walk as a stream_decoder for compressor / decompressor (GPU batches at the end of run()).
+struct block_slice { size_t offset, size; int frame_num, mb_w, mb_h; const block_desc *blocks; size_t n_blocks; const uint8_t *init_states; };
+struct block_feeder : stream_decoder {
+    std::vector<block_slice> slices;
+    compressor *c = nullptr;
+    decompressor *d = nullptr;
+    std::vector<uint8_t> bins;
+    uint8_t cabac_state[1024];
+    void decode_video(hooks *h, int (*read_packet)(void *, uint8_t *, int), void *opaque) override {
+        std::vector<uint8_t> data, chunk(1 << 16);
+        for (;;) {
+            const int got = read_packet(opaque, chunk.data(), int(chunk.size()));
+            if (got <= 0) break;
+            data.insert(data.end(), chunk.begin(), chunk.begin() + got);
+        }
+        if (c) c->set_state_base(cabac_state);
+        if (d) d->set_state_base(cabac_state);
+        int ctx_identity = 0;
+        for (const block_slice &s : slices) {
+            if (s.offset + s.size > data.size()) throw std::runtime_error("feeder: slice outside the stream");
+            memcpy(cabac_state, s.init_states, sizeof cabac_state);
+            void *dec = h->cabac.init_decoder(h->opaque, &ctx_identity, data.data() + s.offset, int(s.size));
+            if (!dec) throw std::runtime_error("feeder: slice not hooked");
+            syntax_walker w{h, dec, cabac_state, {}};
+            w.slice(s.frame_num, s.mb_w, s.mb_h, s.blocks, s.n_blocks);
+            bins.insert(bins.end(), w.bins.begin(), w.bins.end());
+        }
+    }
+};
+
+// CPU-only drivers over the two recorders (no GPU batch: the test codes the records with the oracle)
+struct cpu_compress_driver {
+    h264_model model_;
+    const uint8_t *state_base = nullptr;
+    std::vector<uint16_t> recs;                           // K2 records of all slices
+    std::vector<uint64_t> rec_end;                        // running end per slice
+    struct cabac_decoder {
+        cabac_decoder(cpu_compress_driver *d, const uint8_t *buf, int size) : d_(d), dec_(buf, size_t(size)), rec_(&d->model_) {}
+        ~cabac_decoder() { d_->recs.insert(d_->recs.end(), rec_.records().begin(), rec_.records().end()); d_->rec_end.push_back(d_->recs.size()); }
+        bool hooked() const { return true; }
+        int get(uint8_t *state) { const int s = dec_.get(state); rec_.execute_symbol(s, int(state - d_->state_base)); return s; }
+        int get_bypass() { const int s = dec_.get_bypass(); rec_.execute_symbol(s, kKeyBypass); return s; }
+        int get_terminate() { const int s = dec_.get_terminate() != 0; rec_.execute_symbol(s, kKeyTerminate); return s; }
+        void begin_coding_type(CodingType ct, int z, int p0, int p1) { rec_.begin_coding_type(ct, z, p0, p1); }
+        void end_coding_type(CodingType ct) { rec_.end_coding_type(ct); }
+        cpu_compress_driver *d_; cabac_bin_decoder dec_; compress_recorder rec_;
+    };
+    h264_model *get_model() { return &model_; }
+    std::map<void *, std::unique_ptr<cabac_decoder>> cabac_contexts;
+};
+
+struct cpu_decompress_driver {
+    h264_model model_;
+    const uint8_t *state_base = nullptr;
+    const uint8_t *recoded = nullptr; const uint64_t *recoded_off = nullptr; size_t next = 0;   // per-slice recoded bytes
+    std::vector<uint16_t> recs;                           // K1 records of all slices
+    std::vector<uint64_t> rec_end;
+    struct cabac_decoder {
+        cabac_decoder(cpu_decompress_driver *d, const uint8_t *, int)
+            : d_(d), rec_(&d->model_, d->recoded + d->recoded_off[d->next], size_t(d->recoded_off[d->next + 1] - d->recoded_off[d->next]), d->state_base) { d->next++; }
+        ~cabac_decoder() { d_->recs.insert(d_->recs.end(), rec_.records().begin(), rec_.records().end()); d_->rec_end.push_back(d_->recs.size()); }
+        bool hooked() const { return true; }
+        int get(uint8_t *state) { return rec_.get(state); }
+        int get_bypass() { return rec_.get_bypass(); }
+        int get_terminate() { return rec_.get_terminate(); }
+        void begin_coding_type(CodingType ct, int z, int p0, int p1) { rec_.begin_coding_type(ct, z, p0, p1); }
+        void end_coding_type(CodingType ct) { rec_.end_coding_type(ct); }
+        cpu_decompress_driver *d_; decompress_recorder rec_;
+    };
+    h264_model *get_model() { return &model_; }
+    std::map<void *, std::unique_ptr<cabac_decoder>> cabac_contexts;
+};
+
+// slices described by blocks: spec[3 i ..] = frame_num, mb_width, mb_height; blocks of slice i are
+// blocks[block_off[i] .. block_off[i+1])
+struct model_args {
+    size_t n_slices; const int32_t *spec; const uint64_t *block_off; const block_desc *blocks; const uint8_t *init_states;
+    const uint8_t *payload; const uint64_t *payload_off;      // compress: CABAC bytes; decompress: recoded bytes
+    uint16_t *recs_out; size_t recs_cap; uint64_t *rec_end_out; uint8_t *bins_out; size_t bins_cap; uint64_t *n_bins_out;
+    int decompress;
+};
+
+template <class Driver>
+int model_run_with(Driver &drv, model_args *a) {
+    hooks h = hook_adapter<Driver>::make(&drv);
+    uint8_t cabac_state[1024];
+    drv.state_base = cabac_state;
+    int ctx_identity = 0;
+    size_t n_bins = 0;
+    for (size_t i = 0; i < a->n_slices; i++) {
+        memcpy(cabac_state, a->init_states + 1024 * i, sizeof cabac_state);
+        const uint8_t *buf = a->payload + a->payload_off[i];
+        void *dec = h.cabac.init_decoder(h.opaque, &ctx_identity, buf, int(a->payload_off[i + 1] - a->payload_off[i]));
+        syntax_walker w{&h, dec, cabac_state, {}};
+        auto keep_bins = [&] { for (uint8_t b : w.bins) { if (n_bins < a->bins_cap) a->bins_out[n_bins] = b; n_bins++; } *a->n_bins_out = n_bins; };
+        try {
+            w.slice(a->spec[3 * i], a->spec[3 * i + 1], a->spec[3 * i + 2], a->blocks + a->block_off[i], size_t(a->block_off[i + 1] - a->block_off[i]));
+        } catch (...) { keep_bins(); throw; }             // what was parsed so far helps to see where it went wrong
+        keep_bins();
+    }
+    drv.cabac_contexts.clear();                           // the last decoder hands its records over
+    *a->n_bins_out = n_bins;
+    for (size_t i = 0; i < drv.recs.size() && i < a->recs_cap; i++) a->recs_out[i] = drv.recs[i];
+    for (size_t i = 0; i < drv.rec_end.size(); i++) a->rec_end_out[i] = drv.rec_end[i];
+    return drv.recs.size() <= a->recs_cap && n_bins <= a->bins_cap ? 0 : 2;
+}
+
+int model_run(void *p) {
+    model_args *a = static_cast<model_args *>(p);
+    if (a->decompress) {
+        cpu_decompress_driver drv;
+        drv.recoded = a->payload; drv.recoded_off = a->payload_off;
+        return model_run_with(drv, a);
+    }
+    cpu_compress_driver drv;
+    return model_run_with(drv, a);
+}
+
 int guarded(int (*f)(void *), void *arg, char *err, size_t err_cap) {
     try { return f(arg); }
     catch (const std::exception &e) { snprintf(err, err_cap, "%s", e.what()); return -1; }
@@ -89,7 +257,10 @@ void t_cabac_decode(const uint8_t *bytes, size_t len, const uint16_t *recs, size
 void t_model_trace(const uint16_t *ctx, const uint8_t *sym, const uint8_t *sig, size_t n, uint8_t *pos_out, uint8_t *neg_out,
                    uint64_t *prob_out) {
     h264_model m;
+    m.update_frame_spec(0, 1, 1);                         // the significance-map threshold is applied while the model
+    m.sub_mb_size = 64;                                   // follows a map (recode.cpp:1053): give it a block to follow
     for (size_t i = 0; i < n; i++) {
+        m.mb_coord = CoefficientCoord();
         m.coding_type = PIP_UNKNOWN;
         const model_key key = m.get_model_key(ctx[i]);
         pos_out[i] = uint8_t(m.lookup(key)->pos);
@@ -136,6 +307,24 @@ void t_surrogate(uint64_t seq, size_t size, uint8_t *out) {
     memcpy(out, b.data(), b.size());
 }
 
+// ---- model hooks end to end on the CPU: walk block-described slices through one recorder.
+// compress (decompress = 0): payload = the slices' CABAC bytes, recs_out = K2 range records;
+// decompress (1): payload = the slices' recoded bytes, recs_out = K1 CABAC records.
+int t_model_run(int decompress, size_t n_slices, const int32_t *spec, const uint64_t *block_off, const int32_t *blocks,
+                const uint8_t *init_states, const uint8_t *payload, const uint64_t *payload_off, uint16_t *recs_out,
+                size_t recs_cap, uint64_t *rec_end_out, uint8_t *bins_out, size_t bins_cap, uint64_t *n_bins_out, char *err,
+                size_t err_cap) {
+    model_args a{n_slices, spec, block_off, reinterpret_cast<const block_desc *>(blocks), init_states, payload, payload_off,
+                 recs_out, recs_cap, rec_end_out, bins_out, bins_cap, n_bins_out, decompress};
+    return guarded(model_run, &a, err, err_cap);
+}
+
+// geometry of the model: neighbour of a 4x4 block (out: scan8 index, in-left-mb, in-up-mb)
+void t_neighbor_block(int scan8_index, int above, int32_t *out) {
+    const sub_mb_neighbor n = neighbor_block(scan8_index, above != 0);
+    out[0] = n.scan8_index; out[1] = n.in_left_mb; out[2] = n.in_up_mb;
+}
+
 // ---- the reference's roundtrip (recode.cpp:1601-1640) over a file with recorded slices; GPU.
 // Returns 0 when the reconstruction is byte-identical, 1 when not, -1 on an exception (message in err).
 struct rt_args {
@@ -173,6 +362,40 @@ static int rt_run(void *p) {
     memcpy(a->compressed, compressed.data(), std::min(a->compressed_cap, compressed.size()));
     a->stats[0] = mism; a->stats[1] = hooked;
     return rc;
+}
+
+// roundtrip over a file whose slices are described by residual blocks (model hooks firing); GPU
+struct rtb_args {
+    const uint8_t *file; size_t file_len; size_t n_slices; const uint64_t *offset, *size; const int32_t *spec;
+    const uint64_t *block_off; const block_desc *blocks; const uint8_t *init_states; uint64_t *stats;
+};
+static int rtb_run(void *p) {
+    rtb_args *a = static_cast<rtb_args *>(p);
+    const std::string original(reinterpret_cast<const char *>(a->file), a->file_len);
+    std::vector<uint8_t> bins[2];
+    int pass = 0;
+    struct keeping : stream_decoder {
+        block_feeder f; std::vector<uint8_t> *out;
+        void decode_video(hooks *h, int (*rp)(void *, uint8_t *, int), void *o) override { f.decode_video(h, rp, o); *out = f.bins; }
+    };
+    std::string compressed;
+    const int rc = roundtrip(original, [&](compressor *c, decompressor *d) -> stream_decoder * {
+        keeping *k = new keeping;
+        k->f.c = c; k->f.d = d; k->out = &bins[pass++];
+        for (size_t i = 0; i < a->n_slices; i++)
+            k->f.slices.push_back({size_t(a->offset[i]), size_t(a->size[i]), a->spec[3 * i], a->spec[3 * i + 1], a->spec[3 * i + 2],
+                                   a->blocks + a->block_off[i], size_t(a->block_off[i + 1] - a->block_off[i]), a->init_states + 1024 * i});
+        return k; }, &compressed, 0);
+    a->stats[0] = bins[0].size();
+    a->stats[1] = bins[0] == bins[1];
+    a->stats[2] = compressed.size();
+    return rc;
+}
+int t_roundtrip_blocks(const uint8_t *file, size_t file_len, size_t n_slices, const uint64_t *offset, const uint64_t *size,
+                       const int32_t *spec, const uint64_t *block_off, const int32_t *blocks, const uint8_t *init_states,
+                       uint64_t *stats, char *err, size_t err_cap) {
+    rtb_args a{file, file_len, n_slices, offset, size, spec, block_off, reinterpret_cast<const block_desc *>(blocks), init_states, stats};
+    return guarded(rtb_run, &a, err, err_cap);
 }
 
 int t_roundtrip(const uint8_t *file, size_t file_len, size_t n_slices, const uint64_t *offset, const uint64_t *size,
