@@ -128,4 +128,62 @@ struct RangeEncoder {
     }
 };
 
+// The CABAC instantiation (arithmetic_code<uint32_t, uint16_t, 0x200>, cabac_code.h:18-24) in
+// WRITE-THROUGH form, used by k_cabac_encode.  Every digit is appended as soon as it exists; when low
+// crosses fixed_one the carry (arithmetic_code.h:154-157) is added into the bytes already produced,
+// last byte first -- first the ones still in the 8-byte staging word, then, rarely, the lane's own
+// bytes in HBM, which nobody else touches.  The bytes are the same as with deferral (that is what the
+// reference's deferred digits plus the carry add up to); what changes is the cost of the common
+// case: no certainty test and no held-back state, and since one of a wave's 64 lanes emits on most
+// bins, the length of this path is paid per bin.  (Measured on config 5: held-back form 2.84 ms; this
+// form with a 2-byte store per digit 3.63 ms -- 64 partial-line stores per instruction -- hence the
+// staging word.)
+struct CabacEncoder {
+    static constexpr uint32_t kOne = 0x80000000u;       // fixed_one, arithmetic_code.h:54-55
+    uint32_t low, range;
+    ByteWriter w;
+
+    __device__ __forceinline__ void init(uint32_t initial_range, uint8_t *out, uint32_t capacity) {
+        low = 0; range = initial_range;
+        w.init(out, capacity);
+    }
+    __device__ void carry_back() {
+        const uint32_t r = w.n & 7;                     // bytes still in the staging word
+        if (r) {
+            const uint64_t mask = (uint64_t(1) << (8 * r)) - 1, v = (w.acc & mask) + 1;
+            w.acc = (w.acc & ~mask) | (v & mask);
+            if ((v >> (8 * r)) == 0) return;
+        }
+        uint32_t p = w.n - r;
+        if (p > w.cap) return;                          // overflowed output: nothing stored to carry into
+        while (p > 0) {
+            p--;
+            const uint32_t b = uint32_t(w.base[p]) + 1u;
+            w.base[p] = uint8_t(b);
+            if (b <= 0xffu) break;
+        }
+    }
+    // renormalize_and_emit_digit<uint16_t> (arithmetic_code.h:147-180)
+    __device__ __forceinline__ void emit_digit() {
+        if (__builtin_expect(low >= kOne, 0)) { carry_back(); low -= kOne; }            // :154-159
+        w.put16_even(low >> 15);                                                        // :158, :184-190
+        low = (low & 0x7fffu) << 16;                                                    // :177-178
+        range <<= 16;                                                                   // :179
+    }
+    // finish() (arithmetic_code.h:128-144): stop bit, then 8-bit digits until low is used up
+    __device__ void finish() {
+        for (uint32_t stop = kOne >> 1; stop > 0; stop >>= 1) {                         // :131-137
+            const uint32_t x = (low | stop) & ~(stop - 1);
+            if (stop < range && low <= x && x < uint32_t(low + range)) { low = x; break; }
+        }
+        while (low != 0) {                                                              // :139-142
+            if (low >= kOne) { carry_back(); low -= kOne; }
+            const uint32_t digit = low >> 23;
+            w.put8(digit);
+            low = (low - (digit << 23)) << 8;
+        }
+        range = 0;                                                                      // :143
+    }
+};
+
 }  // namespace avr

@@ -379,21 +379,54 @@ __global__ __launch_bounds__(256) void k_k1p_chain(Plan p, uint32_t total_chunks
     }
     const uint32_t to = from + kChunk < rs[nk] ? from + kChunk : rs[nk];
     uint8_t *so = sorted + p.res_off[s];
-    uint32_t k = me.k_first, at = from;
+    uint32_t k = me.k_first;
     uint32_t st = me.enters_mid ? uint32_t(entry[gc]) : (init[k] & 127u);
+    uint32_t run_end = rs[k + 1];                                // > from: the segment's first position lies in run k
     if (c == 0 && fin) for (uint32_t e = 0; e < k; e++) fin[e] = init[e];       // empty runs before the first bin
-    while (at < to) {
-        const uint32_t run_end = rs[k + 1] < to ? rs[k + 1] : to;
-        uint32_t a = st, b = st;
-        chain_walk<true>(next, so, at, run_end, a, b);
-        at = run_end;
-        if (at == rs[k + 1]) {                                   // the run ends here: its final state, then on to the next
-            if (fin) fin[k] = uint8_t(a);
-            k++;
-            while (k < nk && rs[k + 1] == rs[k]) { if (fin) fin[k] = init[k]; k++; }     // contexts without bins
-            if (k < nk) st = init[k] & 127u;
+    // run k ends at `run_end`: its final state, then on to the next run that has bins
+    auto next_run = [&]() {
+        if (fin) fin[k] = uint8_t(st);
+        k++;
+        while (k < nk && rs[k + 1] == rs[k]) { if (fin) fin[k] = init[k]; k++; }
+        if (k < nk) { st = init[k] & 127u; run_end = rs[k + 1]; } else run_end = 0xffffffffu;
+    };
+    // The segment is walked in aligned 16-byte groups whatever runs it holds (a cold context's run is
+    // a few bins: walking run by run would mean byte loads and stores for most of such a segment).
+    auto group16 = [&](U4 &v, uint32_t at) {
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if (at + 16 <= run_end && at + 16 <= to) {               // no run ends inside
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t sh = (j & 3) * 8, bin = (w[j >> 2] >> sh) & 1u;
+                const uint32_t code = code_context(st, bin);
+                st = chain_next(next, st, bin);
+                w[j >> 2] = (w[j >> 2] & ~(0xffu << sh)) | (code << sh);
+            }
+        } else {
+            for (uint32_t j = 0; j < 16 && at + j < to; j++) {
+                if (at + j == run_end) next_run();
+                const uint32_t sh = (j & 3) * 8, bin = (w[j >> 2] >> sh) & 1u;
+                const uint32_t code = code_context(st, bin);
+                st = chain_next(next, st, bin);
+                w[j >> 2] = (w[j >> 2] & ~(0xffu << sh)) | (code << sh);
+            }
         }
+        v = U4{w[0], w[1], w[2], w[3]};
+    };
+    uint32_t at = from;                                          // a multiple of kChunk; `sorted` is padded past rs[nk]
+    for (; at + 64 <= to; at += 64) {                            // a whole cache line per lane per trip
+        U4 *q = reinterpret_cast<U4 *>(so + at);
+        U4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+        group16(v0, at); group16(v1, at + 16); group16(v2, at + 32); group16(v3, at + 48);
+        q[0] = v0; q[1] = v1; q[2] = v2; q[3] = v3;
     }
+    for (; at < to; at += 16) {
+        U4 *q = reinterpret_cast<U4 *>(so + at);
+        U4 v = q[0];
+        group16(v, at);
+        q[0] = v;
+    }
+    if (to == run_end) next_run();                               // the run (and any empty ones after it) ends with the segment
 }
 
 // A5: one lane per chunk (a quarter of a sort block), its records in stream order.  After the chains

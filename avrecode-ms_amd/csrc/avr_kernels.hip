@@ -62,7 +62,7 @@ struct ChunkSource {
 //     table value with range/2.
 // Returns true when the bin was put_terminate(1): the caller stops and runs finish().
 struct CabacLane {
-    RangeEncoder<uint32_t, 32, 16> e;
+    CabacEncoder e;
     uint32_t lane4;         // 4 * lane: this lane's column in the state dwords
     uint32_t n_states;
     uint32_t scratch;       // byte offset of the lane's scratch dword
