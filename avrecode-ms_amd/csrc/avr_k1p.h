@@ -75,17 +75,26 @@ AVR_HD uint32_t post_lps_range(uint32_t row, uint32_t q, uint32_t *shift) {
     return rl << sh;
 }
 
+// What phases B and C need to know about a resolved code, precomputed per code value (256 entries):
+//   row   rangeTabLPS[p][0..3] of its state, one byte per range quarter (0 for a bypass bin)
+//   meta  bit 0: the coded symbol (1 = the LPS side, cabac_code.h:34; 0 for bypass, whose halving of
+//         the scale, cabac_code.h:52-54, is the extra shift instead); bit 8: bypass
+struct CodeEntry { uint32_t row, meta; };
+AVR_HD CodeEntry code_entry(uint32_t c, const uint32_t *rows /* rows[p], p = pStateIdx */) {
+    if (code_is_bypass(c)) return CodeEntry{0u, 0x100u};
+    return CodeEntry{rows[c >> 2], code_sym(c)};
+}
+
 // One bin on the normalised range, branch-free: returns the renormalisation shift it causes
-// (= bits of output).  rows[p] packs rangeTabLPS[p][0..3], one byte per quarter.
-AVR_HD uint32_t step_range(uint32_t c, const uint32_t *rows, uint32_t *R) {
-    const uint32_t row = rows[c >> 2];
-    const uint32_t rl = (row >> (8 * ((*R >> 6) & 3))) & 0xffu;
+// (= bits of output).  A bypass bin has row 0: rLPS = 0 leaves R alone, and meta adds its one shift.
+AVR_HD uint32_t step_range(const CodeEntry &e, uint32_t *R) {
+    const uint32_t rl = (e.row >> ((*R >> 3) & 24)) & 0xffu;   // quarter (R >> 6) & 3 selects the byte
     const uint32_t rm = *R - rl;                           // MPS side: range - rLPS
-    const uint32_t shm = rm < 256 ? 1u : 0u;
+    const uint32_t shm = ((rm >> 8) & 1u) ^ 1u;            // rm in [128, 511]: one shift iff below 256
     const uint32_t shl = uint32_t(clz32(rl)) - 23;         // LPS side: range = rLPS (cabac_code.h:40-41)
-    const bool byp = code_is_bypass(c), sym = code_sym(c);
-    *R = byp ? *R : (sym ? rl << shl : rm << shm);         // cabac_code.h:52-54: bypass halves the scale only
-    return byp ? 1u : (sym ? shl : shm);
+    const bool sym = e.meta & 1u;
+    *R = sym ? rl << shl : rm << shm;
+    return (sym ? shl : shm) + (e.meta >> 8);
 }
 
 // ------------------------------------------------------------------ phase B1
@@ -154,7 +163,7 @@ AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g)
     if (base < to) for_codes(res, base, to, [&](uint32_t, uint32_t c) { g(c); return false; });
 }
 
-AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const uint32_t *rows, uint32_t max_stretch,
+AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const CodeEntry *codes, uint32_t max_stretch,
                        Stretch *o) {
     const uint32_t lo = chunk * kChunk, limit = lo + kChunk;
     uint32_t R[4], T[4] = {0, 0, 0, 0};
@@ -176,7 +185,7 @@ AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const uin
             return;
         }
         o->first = f;
-        const uint32_t row = rows[res[f] >> 2];
+        const uint32_t row = codes[res[f]].row;
         for (uint32_t q = 0; q < 4; q++) { uint32_t sh; R[q] = post_lps_range(row, q, &sh); }
         i = f + 1;
     }
@@ -187,7 +196,7 @@ AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const uin
         const bool closing = i >= limit && code_is_boundary(c);
         if (closing)
             for (uint32_t q = 0; q < 4; q++) o->exit_q |= uint8_t(((R[q] >> 6) & 3) << (2 * q));
-        for (uint32_t q = 0; q < 4; q++) T[q] += step_range(c, rows, &R[q]);
+        for (uint32_t q = 0; q < 4; q++) T[q] += step_range(codes[c], &R[q]);
         i++;
         if (closing) { closed = true; break; }
     }
@@ -196,14 +205,14 @@ AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const uin
     if (!closed && i < n) {
         const uint32_t interior_end = limit < n ? limit : n;
         if (i < interior_end) {
-            for_codes_all(res, i, interior_end, [&](uint32_t c) { Tm += step_range(c, rows, &Rm); });
+            for_codes_all(res, i, interior_end, [&](uint32_t c) { Tm += step_range(codes[c], &Rm); });
             i = interior_end;
         }
         end = n;
         for_codes(res, i, n, [&](uint32_t idx, uint32_t c) {
             const bool closing = idx >= limit && code_is_boundary(c);
             if (closing) o->exit_q = uint8_t(((Rm >> 6) & 3) * 0x55u);
-            Tm += step_range(c, rows, &Rm);
+            Tm += step_range(codes[c], &Rm);
             if (closing) { end = idx + 1; return true; }
             if (idx - lo > max_stretch) { o->too_long = 1; end = idx + 1; return true; }
             return false;
@@ -259,7 +268,8 @@ AVR_HD uint32_t ref_digits(uint32_t t) { return t <= 21 ? 0 : (t - 21 + 15) / 16
 // window (two digits) with later ones; everything between is its own (argument in DESIGN.md).
 template <class Adder>
 AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, uint32_t chunk,
-                      const uint32_t *rows, Adder &S) {
+                      const uint32_t *rows /* rows[pStateIdx]; measured: the 8-byte per-code entries of B1 are slower here */,
+                      Adder &S) {
     uint32_t R, from;
     if (chunk == 0) { R = 510; from = 0; }
     else { uint32_t sh; R = post_lps_range(rows[res[st.first] >> 2], en.q, &sh); from = st.first + 1; }

@@ -60,21 +60,25 @@ __global__ __launch_bounds__(256) void k_k1p_hist(Plan p, int32_t *status, uint3
         const uint16_t *r = p.recs + p.rec_off[s];
         // 8 records (one 16-byte chunk) per thread per trip; a slice's padding records are no-ops,
         // and i0 is a multiple of 8, so whole chunks can be read up to the padded end
-        bool bad = false;
+        // Records that are no context bin: bypass (selector 1024) and terminate (1025) are the values
+        // 2048..2051; anything else is bad, and so is put_terminate(1) = 2051 anywhere but last.
+        uint32_t worst = 0;                                      // max over non-context records of (record - 2048), wrapping
         for (uint32_t i = i0 + threadIdx.x * 8; i < i1; i += 256 * 8) {
             const uint4 v = *reinterpret_cast<const uint4 *>(r + i);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (uint32_t j = 0; j < 8; j++) {
-                const uint32_t rec = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu, sel = (rec >> 1) & 0x7ffu;
+                const uint32_t rec = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu, sel = rec >> 1;   // sel keeps bits 12..15: a set one is bad too
                 if (i + j < i1) {
                     if (sel < nk) atomicAdd(&cnt[sel], 1u);
-                    else if (sel == AVR_SEL_TERMINATE) bad |= (rec & 1) && i + j + 1 < n;
-                    else bad |= sel != AVR_SEL_BYPASS;
-                    bad |= (rec >> 12) != 0;
+                    else {
+                        const uint32_t t = rec - 2048u + (i + j + 1 == n ? 0u : (rec == 2051u ? 4u : 0u));
+                        worst = worst > t ? worst : t;
+                    }
                 }
             }
         }
+        const bool bad = worst > 3u;
         if (bad) status[s] = AVR_SLICE_BAD_RECORD;
     }
     __syncthreads();
@@ -545,17 +549,23 @@ __global__ __launch_bounds__(64) void k_k1p_replay(Plan p, uint32_t total_chunks
 
 // ------------------------------------------------------------------ phases B1, B2, C
 
+// code_entry() from the device copy of the tables (d_tables.packed[2 p][0] = rangeTabLPS[p][0..3])
+__device__ __forceinline__ CodeEntry device_code_entry(uint32_t c) {
+    if (code_is_bypass(c)) return CodeEntry{0u, 0x100u};
+    return CodeEntry{d_tables.packed[2 * (c >> 2)][0], code_sym(c)};
+}
+
 __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, const uint8_t *res,
                                                 const int32_t *status, Stretch *st, uint32_t max_stretch) {
-    __shared__ uint32_t rows[64];
-    if (threadIdx.x < 64) rows[threadIdx.x] = d_tables.packed[2 * threadIdx.x][0];
+    __shared__ CodeEntry codes[256];
+    codes[threadIdx.x] = device_code_entry(threadIdx.x);
     __syncthreads();
     const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
     if (gc >= total_chunks) return;
     const uint32_t slice = p.chunk_slice[gc];
     if (status[slice] != AVR_SLICE_OK) { st[gc].first = kNone; st[gc].too_long = 0; return; }
     Stretch o;
-    b1_stretch(res + p.res_off[slice], p.n_bins[slice], gc - p.chunk_base[slice], rows, max_stretch, &o);
+    b1_stretch(res + p.res_off[slice], p.n_bins[slice], gc - p.chunk_base[slice], codes, max_stretch, &o);
     st[gc] = o;
 }
 

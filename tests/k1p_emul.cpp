@@ -50,10 +50,12 @@ int k1p_emul_resolve(const uint16_t *recs, size_t n, uint8_t *states, size_t n_s
 size_t k1p_emul_encode_resolved(const uint8_t *res, size_t n, uint8_t *out, size_t cap, uint32_t *info) {
     uint32_t rows[64];
     for (int p = 0; p < 64; p++) rows[p] = kT.packed[2 * p][0];
+    CodeEntry codes[256];
+    for (uint32_t c = 0; c < 256; c++) codes[c] = code_entry(c, rows);
     const uint32_t n_chunks = n ? uint32_t((n + kChunk - 1) / kChunk) : 1;
     std::vector<Stretch> st(n_chunks);
     std::vector<Entry> en(n_chunks);
-    for (uint32_t c = 0; c < n_chunks; c++) b1_stretch(res, uint32_t(n), c, rows, kMaxStretch, &st[c]);
+    for (uint32_t c = 0; c < n_chunks; c++) b1_stretch(res, uint32_t(n), c, codes, kMaxStretch, &st[c]);
     SliceTotals tot;
     b2_chain(st.data(), n_chunks, en.data(), &tot);
     const uint32_t nd = ref_digits(tot.t_total);
