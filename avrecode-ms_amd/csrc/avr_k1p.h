@@ -78,11 +78,12 @@ AVR_HD uint32_t post_lps_range(uint32_t row, uint32_t q, uint32_t *shift) {
 // What phases B and C need to know about a resolved code, precomputed per code value (256 entries):
 //   row   rangeTabLPS[p][0..3] of its state, one byte per range quarter (0 for a bypass bin)
 //   meta  bit 0: the coded symbol (1 = the LPS side, cabac_code.h:34; 0 for bypass, whose halving of
-//         the scale, cabac_code.h:52-54, is the extra shift instead); bit 8: bypass
+//         the scale, cabac_code.h:52-54, is the extra shift instead); bit 1: the bin adds to low
+//         (the symbol again, or for bypass the bin); bit 8: bypass
 struct CodeEntry { uint32_t row, meta; };
 AVR_HD CodeEntry code_entry(uint32_t c, const uint32_t *rows /* rows[p], p = pStateIdx */) {
-    if (code_is_bypass(c)) return CodeEntry{0u, 0x100u};
-    return CodeEntry{rows[c >> 2], code_sym(c)};
+    if (code_is_bypass(c)) return CodeEntry{0u, 0x100u | ((c & 1u) << 1)};
+    return CodeEntry{rows[c >> 2], code_sym(c) * 3u};
 }
 
 // One bin on the normalised range, branch-free: returns the renormalisation shift it causes
@@ -266,41 +267,76 @@ AVR_HD uint32_t ref_digits(uint32_t t) { return t <= 21 ? 0 : (t - 21 + 15) / 16
 //   void add(uint32_t digit_index, uint32_t v)     shared position, atomic add
 // A stretch shares its first two digits with the windows of earlier stretches and its final
 // window (two digits) with later ones; everything between is its own (argument in DESIGN.md).
+//
+// The coder is kept in normalised form: R in [256, 511] as in B1, and low as a 64-bit integer L2 in
+// units of half the reference's scale, i.e. with the reference's range R << e (arithmetic_code.h:107-114,
+// cabac_code.h:37-41) L2 = 2 * low >> e, which is exact: every term of low is a multiple of the
+// scale it was added at, and a bypass bin's R/2 (cabac_code.h:52-54) is what the factor 2 is for.
+// A 16-bit digit of the code string is due whenever e drops to 0 or below (arithmetic_code.h:115-122);
+// in this form that is just a bit position `sp` = 15 - e of L2/2 reaching 15.  Nothing forces the
+// digit out at that very bin: L2 has room for 4 more bins, so the bulk loop looks after every 4th
+// bin, at the same place for every lane of a wave -- where the reference's form has one lane or
+// another emitting at almost every bin.  A digit taken late has the carries of the bins in between
+// already in it (it can reach 2^17); the sums are integers and phase D carries them on.
 template <class Adder>
 AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, uint32_t chunk,
-                      const uint32_t *rows /* rows[pStateIdx]; measured: the 8-byte per-code entries of B1 are slower here */,
-                      Adder &S) {
+                      const CodeEntry *codes, Adder &S) {
     uint32_t R, from;
     if (chunk == 0) { R = 510; from = 0; }
-    else { uint32_t sh; R = post_lps_range(rows[res[st.first] >> 2], en.q, &sh); from = st.first + 1; }
+    else { uint32_t sh; R = post_lps_range(codes[res[st.first]].row, en.q, &sh); from = st.first + 1; }
     const uint32_t phase = en.t_start & 15, g0 = en.t_start >> 4;
-    // local coder in the reference's form, pre-shifted so its digits sit on the global digit grid
-    uint32_t low = 0, range = R << (22 - phase);
-    uint32_t j = 0, prev = 0;                              // digits produced; the last one, held one step
-    for_codes_all(res, from, st.end, [&](uint32_t c) {
-        const int norm = 23 - clz32(range);                // cabac_code.h:37
-        const uint32_t q = (range >> (norm + 6)) & 3;      // :39-40
-        const uint32_t rt = ((rows[c >> 2] >> (8 * q)) & 0xffu) << norm;   // :40-41, :60
-        const uint32_t r1 = code_is_bypass(c) ? range >> 1 : rt;           // :53
-        const uint32_t r0 = range - r1;                    // arithmetic_code.h:107-114
-        const bool sym = code_sym(c);
-        low += sym ? r0 : 0u;
-        range = sym ? r1 : r0;
-        if (range < 0x200u) {                              // arithmetic_code.h:115-122: one 16-bit digit
-            const uint32_t carry = low >> 31, digit = (low >> 15) & 0xffffu;
-            if (j > 0) {                                   // release the held digit with the carry it just received
-                if (j - 1 < 2) S.add(g0 + j - 1, prev + carry); else S.store(g0 + j - 1, prev + carry);
-            }
-            prev = digit;
+    uint64_t L2 = 0;
+    int sp = int(phase) - 7;                               // e = 22 - phase at the start (cabac_code.h:30 shifted onto the digit grid)
+    uint32_t j = 0;                                        // digits produced
+    auto bin = [&](uint32_t c) {
+        const CodeEntry e = codes[c];
+        const uint32_t rl = (e.row >> ((R >> 3) & 24)) & 0xffu;
+        const uint32_t rm = R - rl;
+        const uint32_t shm = ((rm >> 8) & 1u) ^ 1u;
+        const uint32_t shl = uint32_t(clz32(rl)) - 23;
+        const bool sym = e.meta & 1u, byp = e.meta >> 8;
+        const uint32_t v = byp ? R : 2 * rm;               // what a 1 adds to low, in half units
+        const uint32_t sh = (sym ? shl : shm) + (e.meta >> 8);
+        L2 = (L2 + ((e.meta & 2u) ? v : 0u)) << sh;
+        R = sym ? rl << shl : rm << shm;
+        sp += int(sh);
+    };
+    auto digits = [&]() {                                  // every digit that is due, oldest (topmost) first
+        while (sp >= 15) {
+            const uint32_t d = uint32_t(L2 >> (sp + 1));
+            L2 &= (uint64_t(2) << sp) - 1;
+            if (j < 2) S.add(g0 + j, d); else S.store(g0 + j, d);
             j++;
-            low = (low & 0x7fffu) << 16;
-            range <<= 16;
+            sp -= 16;
         }
-    });
-    // what is left: the held digit (+ the window's carry bit) and the 31-bit window itself
-    if (j > 0) S.add(g0 + j - 1, prev + (low >> 31));
-    S.add(g0 + j, (low >> 15) & 0xffffu);
-    S.add(g0 + j + 1, (low & 0x7fffu) << 1);
+    };
+    const uint32_t to = st.end;
+    if (from < to) {
+        const uint32_t head_end = ((from + 63) & ~63u) < to ? ((from + 63) & ~63u) : to;
+        for_codes(res, from, head_end, [&](uint32_t, uint32_t c) { bin(c); digits(); return false; });
+        uint32_t base = head_end;
+        for (; base + 64 <= to; base += 64) {              // a whole cache line per lane per trip (see for_codes_all)
+            const U4 *p = reinterpret_cast<const U4 *>(res + base);
+            const U4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+            const uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 4
+#endif
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t d = w[k];
+                bin(d & 0xffu); bin((d >> 8) & 0xffu); bin((d >> 16) & 0xffu); bin(d >> 24);
+                digits();                                  // 4 bins shift by at most 28: sp <= 14 + 28, L2 < 2^61
+            }
+        }
+        if (base < to) for_codes(res, base, to, [&](uint32_t, uint32_t c) { bin(c); digits(); return false; });
+    }
+    // what is left is the coder's window: the top of digit g0 + j (with any carry) and 15 - e bits of the next
+    if (sp >= 0) {
+        S.add(g0 + j, uint32_t(L2 >> (sp + 1)));
+        S.add(g0 + j + 1, uint32_t(L2 & ((uint64_t(2) << sp) - 1)) << (15 - sp));
+    } else {
+        S.add(g0 + j, uint32_t(L2 << (-sp - 1)) );
+    }
 }
 
 // ------------------------------------------------------------------ phase D (one lane per slice)

@@ -551,8 +551,8 @@ __global__ __launch_bounds__(64) void k_k1p_replay(Plan p, uint32_t total_chunks
 
 // code_entry() from the device copy of the tables (d_tables.packed[2 p][0] = rangeTabLPS[p][0..3])
 __device__ __forceinline__ CodeEntry device_code_entry(uint32_t c) {
-    if (code_is_bypass(c)) return CodeEntry{0u, 0x100u};
-    return CodeEntry{d_tables.packed[2 * (c >> 2)][0], code_sym(c)};
+    if (code_is_bypass(c)) return CodeEntry{0u, 0x100u | ((c & 1u) << 1)};
+    return CodeEntry{d_tables.packed[2 * (c >> 2)][0], code_sym(c) * 3u};
 }
 
 __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, const uint8_t *res,
@@ -630,8 +630,8 @@ struct DeviceAdder {
 __global__ __launch_bounds__(256) void k_k1p_c(Plan p, uint32_t total_chunks, const uint8_t *res,
                                                const Stretch *st, const Entry *en, const SliceTotals *tot,
                                                uint32_t *S) {
-    __shared__ uint32_t rows[64];
-    if (threadIdx.x < 64) rows[threadIdx.x] = d_tables.packed[2 * threadIdx.x][0];
+    __shared__ CodeEntry codes[256];
+    codes[threadIdx.x] = device_code_entry(threadIdx.x);
     __syncthreads();
     const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
     if (gc >= total_chunks) return;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void k_k1p_c(Plan p, uint32_t total_chunks, co
     const uint32_t slice = p.chunk_slice[gc];
     if (tot[slice].bad) return;
     DeviceAdder add{S + p.dig_off[slice]};
-    c_stretch(res + p.res_off[slice], o, en[gc], gc - p.chunk_base[slice], rows, add);
+    c_stretch(res + p.res_off[slice], o, en[gc], gc - p.chunk_base[slice], codes, add);
 }
 
 // ------------------------------------------------------------------ phase D

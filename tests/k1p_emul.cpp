@@ -63,7 +63,7 @@ size_t k1p_emul_encode_resolved(const uint8_t *res, size_t n, uint8_t *out, size
     HostAdder add{S};
     uint32_t active = 0;
     for (uint32_t c = 0; c < n_chunks; c++)
-        if (st[c].first != kNone) { c_stretch(res, st[c], en[c], c, rows, add); active++; }
+        if (st[c].first != kNone) { c_stretch(res, st[c], en[c], c, codes, add); active++; }
     const uint32_t len = d_slice(S.data(), tot, out, uint32_t(cap));
     if (info) {
         info[0] = active; info[1] = tot.t_total; info[2] = tot.r_final; info[3] = tot.bad;
