@@ -240,10 +240,11 @@ def main():
             "dtype": "u32" if kind == avr.KIND_CABAC else "u64", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[args.workload], "kernel": "K1 cabac_encode" if kind == avr.KIND_CABAC else "K2 range_encode",
                        "slices_per_gpu": n_slices, "bins_per_gpu": w.total_bins, "h264_bytes_per_gpu": out_bytes,
-                       "n_states": w.n_states, "n_states_declared": declared_states, "layout": "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
+                       "n_states": w.n_states, "n_states_declared": declared_states,
+                       "layout": "slice-major" if path == "chunked" else "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("K1p: k_k1p_{hist,scan,scatter,spec,link,chain,gather,b1,b2,zero,c,d} (one step = 13 launches; "
+                         "kernel": ("K1p: k_k1p_{hist,scan,scatter,spec,link,chain,replay,b1,b2,zero,c,d} (one step = 13 launches; "
                                     "largest: k_k1p_scatter)" if path == "chunked" else "k_cabac_encode<tiled>")
                          if kind == avr.KIND_CABAC else "k_range_encode<tiled>",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,

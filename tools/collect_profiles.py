@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Turn one tools/gpu_final.sh run (gpurun_out/TAG/) into the committed summaries under profiles/:
+   python tools/collect_profiles.py TAG ROUND        e.g.  fin2 r01
+kernel-trace stats and the PMC counter files are copied as they are (kernels of this library only for
+the counters); pmc_traffic.json is what bench.py's roofline.traffic reads."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, rnd = sys.argv[1], sys.argv[2]
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    if not hits:
+        raise SystemExit(f"missing {pattern} under {src}")
+    return hits[0]
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").replace("avr::", "")
+
+
+def per_kernel(path, counter, steps_key="avr::"):
+    """mean counter value per launch, per kernel of this library, skipping the warm-up step's launches"""
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and "avr::" in r["Kernel_Name"]
+            and "synth" not in r["Kernel_Name"] and "context_" not in r["Kernel_Name"] and "states_permute" not in r["Kernel_Name"]
+            and "pack_tiles" not in r["Kernel_Name"]]
+    by = collections.defaultdict(list)
+    for r in rows:
+        by[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return {k: sum(v[1:]) / max(len(v) - 1, 1) if len(v) > 1 else v[0] for k, v in by.items()}   # first launch = warm-up
+
+
+traffic = {}
+for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches of one step"),
+                      (5, "cabac_serial_w5_s1048576", "k_cabac_encode<tiled>")):
+    shutil.copy(one(f"w{w}_stats/**/*kernel_stats.csv"), os.path.join(dst, f"{rnd}_w{w}_kernel_stats.csv"))
+    for what in ("fetch", "write"):
+        rows = [r for r in csv.DictReader(open(one(f"w{w}_{what}/**/*counter_collection.csv"))) if "avr::" in r["Kernel_Name"]]
+        with open(os.path.join(dst, f"{rnd}_w{w}_pmc_{what}.csv"), "w", newline="") as f:
+            wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            wr.writeheader()
+            wr.writerows(rows)
+    fetch = per_kernel(one(f"w{w}_fetch/**/*counter_collection.csv"), "FETCH_SIZE")
+    write = per_kernel(one(f"w{w}_write/**/*counter_collection.csv"), "WRITE_SIZE")
+    fsum, wsum = sum(fetch.values()), sum(write.values())
+    traffic[key] = {
+        "kernel": label, "FETCH_SIZE_KB_raw_sum": fsum, "WRITE_SIZE_KB_raw_sum": wsum,
+        "fetch_bytes_corrected_x2": fsum * 1024 * 2, "write_bytes": wsum * 1024,
+        "hbm_bytes_per_launch": fsum * 1024 * 2 + wsum * 1024,
+        "per_kernel_FETCH_SIZE_KB": fetch, "per_kernel_WRITE_SIZE_KB": write,
+        "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE), averaged over the launches of the timed steps; FETCH_SIZE "
+                "doubled per the gfx950 wide-read rule (uncalibrated for byte gathers)"}
+    # issue / wait counters of the same workload, one line per kernel
+    sq = one(f"w{w}_sq/**/*counter_collection.csv")
+    agg, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(sq)):
+        if "avr::" in r["Kernel_Name"] and "synth" not in r["Kernel_Name"]:
+            k = (short(r["Kernel_Name"]), r["Counter_Name"])
+            agg[k] += float(r["Counter_Value"]); cnt[k] += 1
+    names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"]
+    with open(os.path.join(dst, f"{rnd}_w{w}_pmc_sq.csv"), "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["kernel"] + names)
+        for k in sorted({k[0] for k in agg}):
+            wr.writerow([k] + ["%.6g" % (agg[(k, c)] / max(cnt[(k, c)], 1)) for c in names])
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+for b in ("w2", "w3", "w4", "w5", "w5_k2", "w2_resolved"):
+    p = os.path.join(src, f"bench_{b}.json")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, f"{rnd}_bench_{b}.json"))
+for key, t in traffic.items():
+    print(key, "HBM bytes per step: %.3f GB" % (t["hbm_bytes_per_launch"] / 1e9))
+for b in ("w2", "w3", "w4", "w5", "w5_k2", "w2_resolved"):
+    p = os.path.join(dst, f"{rnd}_bench_{b}.json")
+    if os.path.exists(p):
+        j = json.loads(open(p).read().strip().splitlines()[-1])
+        print(b, "%.3f ms  %.2f GB/s  frac %.4f" % (j["ms_per_step"], j["value"] / 1e9, j["roofline"]["frac"]),
+              ("cpu %.0f MB/s x%.1f %s" % (j["cpu_baseline"]["value"] / 1e6, j["gpu_over_cpu"], j["cpu_baseline"].get("parity_vs_gpu")))
+              if "cpu_baseline" in j else "")
