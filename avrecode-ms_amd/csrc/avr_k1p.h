@@ -190,16 +190,22 @@ AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const Cod
         for (uint32_t q = 0; q < 4; q++) { uint32_t sh; R[q] = post_lps_range(row, q, &sh); }
         i = f + 1;
     }
-    // until the four candidates have merged (a few bins): byte-wise
+    // until the four candidates have merged (a few bins)
     bool closed = false;
-    while (i < n && !(R[0] == R[1] && R[1] == R[2] && R[2] == R[3])) {
-        const uint32_t c = res[i];
-        const bool closing = i >= limit && code_is_boundary(c);
-        if (closing)
-            for (uint32_t q = 0; q < 4; q++) o->exit_q |= uint8_t(((R[q] >> 6) & 3) << (2 * q));
-        for (uint32_t q = 0; q < 4; q++) T[q] += step_range(codes[c], &R[q]);
-        i++;
-        if (closing) { closed = true; break; }
+    if (i < n) {
+        uint32_t i_next = n;
+        for_codes(res, i, n, [&](uint32_t idx, uint32_t c) {
+            if (R[0] == R[1] && R[1] == R[2] && R[2] == R[3]) { i_next = idx; return true; }
+            const bool closing = idx >= limit && code_is_boundary(c);
+            if (closing)
+                for (uint32_t q = 0; q < 4; q++) o->exit_q |= uint8_t(((R[q] >> 6) & 3) << (2 * q));
+            const CodeEntry e = codes[c];
+            for (uint32_t q = 0; q < 4; q++) T[q] += step_range(e, &R[q]);
+            i_next = idx + 1;
+            if (closing) { closed = true; return true; }
+            return false;
+        });
+        i = i_next;
     }
     // merged: one range, 16 codes per load.  Below `limit` no bin can close the stretch.
     uint32_t Rm = R[0], Tm = 0, end = i;

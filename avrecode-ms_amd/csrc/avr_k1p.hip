@@ -9,7 +9,8 @@
 //   k_k1p_spec      A4a lane per sorted segment     walk the entered run from the two extreme states
 //   k_k1p_link      A4b lane per sorted segment     true entry state of every segment
 //   k_k1p_chain     A4c lane per sorted segment     state before each bin (cabac_code.h:43-47) -> resolved codes
-//   k_k1p_replay    A5  lane per sort block         resolved code of every bin, in stream order
+//   k_k1p_entry     A5a thread per 4 contexts       state of every context at the start of every chunk
+//   k_k1p_replay    A5b lane per chunk              resolved code of every bin, in stream order
 //   k_k1p_b1        B1  lane per chunk              stretch summaries for the 4 entry quarters
 //   k_k1p_b2        B2  lane per slice              chain the summaries: entry range + bit position
 //   k_k1p_zero          workgroup per slice         zero the digit sums that will be used
@@ -447,8 +448,40 @@ __global__ __launch_bounds__(256) void k_k1p_chain(Plan p, uint32_t total_chunks
 // both resolved codes:  T[st] = next if MPS | next if LPS << 8 | code(bin 0) << 16 | code(bin 1) << 24.
 constexpr uint32_t kStBypass = 128, kStTerminate = 129, kStPad = 130, kStNone = 131, kReplayTable = 192;
 
-__global__ __launch_bounds__(64) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *qoff,
-                                                   const uint8_t *sorted, const uint8_t *init_states, uint8_t *res,
+// The entry states of every chunk, four contexts per thread: est[chunk][k] = state of context k at the
+// chunk's first bin, read off the resolved code at the sorted position where the chunk's bins of k
+// start (a context without a bin from there on gets whatever lies at the end of its run: it is never
+// looked at).  Done apart from the replay so that a replay lane starts from independent loads.
+__global__ __launch_bounds__(256) void k_k1p_entry(Plan p, uint32_t total_chunks, const int32_t *status, const uint32_t *qoff,
+                                                  const uint8_t *sorted, const uint8_t *init_states, uint32_t *est,
+                                                  uint32_t chunks_per_block, uint32_t recip) {
+    // Consecutive threads take consecutive context groups of one chunk: the chunk's offsets are read and
+    // its states written as one contiguous row.  (Measured: chunk-minor threads with est[kw][chunk], which
+    // would make the sorted-order reads neighbours instead, is 3x slower: the offset reads become strided.)
+    // A workgroup takes chunks_per_block = 256 / nkw whole rows; thread -> (row, group) by a multiply with
+    // recip = ceil(2^16 / nkw), exact for thread ids below 256.
+    const uint32_t nk = p.n_states, nkw = (nk + 3) >> 2;
+    const uint32_t row = (threadIdx.x * recip) >> 16, kw = threadIdx.x - row * nkw, k0 = kw * 4;
+    const uint32_t gc = blockIdx.x * chunks_per_block + row;
+    if (row >= chunks_per_block || gc >= total_chunks) return;
+    const uint32_t s = p.chunk_slice[gc];
+    if (status[s] != AVR_SLICE_OK) return;
+    const uint32_t c = gc - p.chunk_base[s];
+    if (c * kChunk >= p.n_bins[s]) return;
+    const uint8_t *so = sorted + p.res_off[s];
+    const uint32_t *bo = qoff + (size_t(p.blk_base[s]) * 4 + c) * nk;    // chunk c is quarter c & 3 of sort block c >> 2
+    const uint8_t *init = init_states + size_t(s) * nk;
+    uint32_t word = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t k = k0 + j < nk ? k0 + j : nk - 1;
+        const uint32_t cd = so[bo[k]];
+        word |= (cd < 252 ? cd >> 1 : init[k] & 127u) << (8 * j);           // pStateIdx 63 never moves
+    }
+    est[size_t(gc) * nkw + kw] = word;
+}
+
+__global__ __launch_bounds__(64) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *est, uint8_t *res,
                                                    const int32_t *status) {
     extern __shared__ uint32_t replay_lds[];                     // T[kReplayTable], then state dwords [(nk+8)/4][64]
     uint32_t *T = replay_lds;
@@ -474,25 +507,9 @@ __global__ __launch_bounds__(64) void k_k1p_replay(Plan p, uint32_t total_chunks
     const uint32_t i1 = i0 + kChunk < n ? i0 + kChunk : n;
     if (i0 >= n) return;
     {
-        // chunk c is quarter c & 3 of the slice's sort block c >> 2.  A context without a bin from here
-        // on gets whatever lies at the end of its run: it is never looked at.
-        const uint8_t *so = sorted + p.res_off[s];
-        const uint32_t *bo = qoff + (size_t(p.blk_base[s]) * 4 + c) * nk;
-        const uint8_t *init = init_states + size_t(s) * nk;
-        for (uint32_t k0 = 0; k0 < nk; k0 += 4) {
-            uint32_t at[4], in[4], cd[4], word = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t k = k0 + j < nk ? k0 + j : nk - 1;
-                at[j] = bo[k];
-                in[j] = init[k];
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) cd[j] = so[at[j]];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) word |= (cd[j] < 252 ? cd[j] >> 1 : in[j] & 127u) << (8 * j);   // pStateIdx 63 never moves
-            *reinterpret_cast<uint32_t *>(stb + k0 * 64) = word;
-        }
+        const uint32_t nkw = (nk + 3) >> 2;
+        const uint32_t *e = est + size_t(gc) * nkw;
+        for (uint32_t kw = 0; kw < nkw; kw++) *reinterpret_cast<uint32_t *>(stb + kw * 256) = e[kw];
         const uint32_t pseudo[5] = {kStNone, kStBypass, kStTerminate, kStPad, kStNone};
 #pragma unroll
         for (uint32_t j = 0; j < 5; j++) stb[((nk + j) >> 2) * 256 + ((nk + j) & 3)] = uint8_t(pseudo[j]);
@@ -743,7 +760,8 @@ static hipError_t launch_resolve(hipStream_t s, const Plan &p, uint32_t n_slices
     uint32_t *run_start = reinterpret_cast<uint32_t *>(w);   w += up256(n_slices * uint64_t(n_states + 1) * 4 + 16);
     Seg *seg = reinterpret_cast<Seg *>(w);                   w += up256(uint64_t(pl->total_chunks) * sizeof(Seg));
     uint8_t *entry = w;                                      w += up256(uint64_t(pl->total_chunks) + 16);
-    uint32_t *qoff = reinterpret_cast<uint32_t *>(w);
+    uint32_t *qoff = reinterpret_cast<uint32_t *>(w);        w += up256(uint64_t(pl->total_blocks) * n_states * 16 + 16);
+    uint32_t *est = reinterpret_cast<uint32_t *>(w);
     uint32_t key_bits = 0;
     while ((1u << key_bits) < n_states) key_bits++;
     const uint32_t chunk_blocks = (pl->total_chunks + 255) / 256;
@@ -761,8 +779,12 @@ static hipError_t launch_resolve(hipStream_t s, const Plan &p, uint32_t n_slices
                            sorted, seg, entry, final_states);
     }
     const uint32_t replay_lds = kReplayTable * 4 + ((n_states + 8) / 4) * 256;
-    hipLaunchKernelGGL(k_k1p_replay, dim3((pl->total_chunks + 63) / 64), dim3(64), replay_lds, s, p, pl->total_chunks, qoff,
-                       sorted, init_states, res, status);
+    if (n_states > 0) {
+        const uint32_t nkw = (n_states + 3) / 4, cpb = 256 / nkw;           // nkw <= 256
+        hipLaunchKernelGGL(k_k1p_entry, dim3((pl->total_chunks + cpb - 1) / cpb), dim3(256), 0, s, p, pl->total_chunks, status, qoff,
+                           sorted, init_states, est, cpb, (65536 + nkw - 1) / nkw);
+    }
+    hipLaunchKernelGGL(k_k1p_replay, dim3((pl->total_chunks + 63) / 64), dim3(64), replay_lds, s, p, pl->total_chunks, est, res, status);
     return hipGetLastError();
 }
 
@@ -786,7 +808,8 @@ static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, c
 static inline uint64_t resolve_ws_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl) {
     return up256(pl->res_total + 32) + up256(uint64_t(pl->total_blocks) * n_states * 4 + 16) +
            up256(n_slices * uint64_t(n_states + 1) * 4 + 16) + up256(uint64_t(pl->total_chunks) * sizeof(Seg)) +
-           up256(uint64_t(pl->total_chunks) + 16) + up256(uint64_t(pl->total_blocks) * n_states * 16 + 16);
+           up256(uint64_t(pl->total_chunks) + 16) + up256(uint64_t(pl->total_blocks) * n_states * 16 + 16) +
+           up256(uint64_t(pl->total_chunks) * ((n_states + 3) / 4) * 4 + 16);
 }
 
 size_t k1p_code_workspace_bytes(size_t n_slices, const avr_chunk_plan *pl);
