@@ -128,7 +128,7 @@ __global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, uint32_t *hist, uint3
 // form spent 75 % of its wave cycles stalled on issuing those stores).
 constexpr uint32_t kQuarter = kSortBlock / 4, kQuarterBatches = kQuarter / 64;
 
-__global__ __launch_bounds__(256) void k_k1p_scatter(Plan p, const int32_t *status, const uint32_t *boff,
+__global__ __launch_bounds__(256, 8) void k_k1p_scatter(Plan p, const int32_t *status, const uint32_t *boff,
                                                      const uint32_t *run_start, uint8_t *sorted, uint32_t *qoff,
                                                      uint32_t key_bits) {
     // LDS (dynamic, sized by the number of contexts so that more blocks fit a CU):
