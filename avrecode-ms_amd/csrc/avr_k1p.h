@@ -42,6 +42,16 @@
 namespace avr {
 namespace k1p {
 
+// Keep a value where it is computed (an empty asm statement the optimiser cannot look through): used to
+// make a batch of independent LDS table reads issue together, ahead of the dependent arithmetic --
+// hipcc otherwise sinks each read to its use, behind the previous bin's result, and every bin waits
+// out a full LDS latency.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AVR_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#else
+#define AVR_PIN2(a, b) ((void)0)
+#endif
+
 constexpr uint32_t kChunk = 1024;              // bins per fixed chunk (one lane of B1 / C)
 constexpr uint32_t kNone = 0xffffffffu;
 constexpr uint32_t kMaxStretch = 16 * kChunk;  // a longer stretch sends the slice to the serial kernel
@@ -94,8 +104,9 @@ AVR_HD uint32_t step_range(const CodeEntry &e, uint32_t *R) {
     const uint32_t shm = ((rm >> 8) & 1u) ^ 1u;            // rm in [128, 511]: one shift iff below 256
     const uint32_t shl = uint32_t(clz32(rl)) - 23;         // LPS side: range = rLPS (cabac_code.h:40-41)
     const bool sym = e.meta & 1u;
-    *R = sym ? rl << shl : rm << shm;
-    return (sym ? shl : shm) + (e.meta >> 8);
+    const uint32_t sh = sym ? shl : shm;                   // selects, not a branch: both sides are two instructions
+    *R = (sym ? rl : rm) << sh;
+    return sh + (e.meta >> 8);
 }
 
 // ------------------------------------------------------------------ phase B1
@@ -138,10 +149,9 @@ AVR_HD void for_codes(const uint8_t *res, uint32_t from, uint32_t n, F &&f) {
 // index, no early exit.  The bulk is taken 64 bytes per lane per trip (four 16-byte loads issued
 // together): lanes stream from addresses a kilobyte apart, so a 16-byte load drags in a whole
 // cache line per lane and nothing keeps it resident until the lane comes back for the rest.
-template <class G>
-AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g) {
+template <class G, class G4>
+AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g, G4 &&g4) {
     if (from >= to) return;
-    auto four = [&](uint32_t d) { g(d & 0xffu); g((d >> 8) & 0xffu); g((d >> 16) & 0xffu); g(d >> 24); };
     auto group16 = [&](const U4 &v) {
         uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -150,18 +160,29 @@ AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g)
         for (uint32_t k = 0; k < 4; k++) {
             const uint32_t d = w0;
             w0 = w1; w1 = w2; w2 = w3;
-            four(d);
+            g4(d);                                         // four codes, first in the low byte
         }
     };
     const uint32_t head_end = ((from + 63) & ~63u) < to ? ((from + 63) & ~63u) : to;
     for_codes(res, from, head_end, [&](uint32_t, uint32_t c) { g(c); return false; });
     uint32_t base = head_end;
-    for (; base + 64 <= to; base += 64) {
+    if (base + 64 <= to) {                                 // the next line is in flight while this one is worked on
         const U4 *p = reinterpret_cast<const U4 *>(res + base);
-        const U4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-        group16(v0); group16(v1); group16(v2); group16(v3);
+        U4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        for (; base + 64 <= to; base += 64) {
+            U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
+            if (base + 128 <= to) { const U4 *q = reinterpret_cast<const U4 *>(res + base + 64); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+            group16(v0); group16(v1); group16(v2); group16(v3);
+            v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+        }
     }
     if (base < to) for_codes(res, base, to, [&](uint32_t, uint32_t c) { g(c); return false; });
+}
+
+// The table entries of the four codes in a dword, read together (see AVR_PIN2).
+AVR_HD void code_entries4(const CodeEntry *codes, uint32_t d, CodeEntry e[4]) {
+    e[0] = codes[d & 0xffu]; e[1] = codes[(d >> 8) & 0xffu]; e[2] = codes[(d >> 16) & 0xffu]; e[3] = codes[d >> 24];
+    AVR_PIN2(e[0].row, e[0].meta); AVR_PIN2(e[1].row, e[1].meta); AVR_PIN2(e[2].row, e[2].meta); AVR_PIN2(e[3].row, e[3].meta);
 }
 
 AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const CodeEntry *codes, uint32_t max_stretch,
@@ -212,7 +233,13 @@ AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const Cod
     if (!closed && i < n) {
         const uint32_t interior_end = limit < n ? limit : n;
         if (i < interior_end) {
-            for_codes_all(res, i, interior_end, [&](uint32_t c) { Tm += step_range(codes[c], &Rm); });
+            for_codes_all(res, i, interior_end, [&](uint32_t c) { Tm += step_range(codes[c], &Rm); },
+                          [&](uint32_t d) {
+                              CodeEntry e[4];
+                              code_entries4(codes, d, e);
+                              Tm += step_range(e[0], &Rm); Tm += step_range(e[1], &Rm);
+                              Tm += step_range(e[2], &Rm); Tm += step_range(e[3], &Rm);
+                          });
             i = interior_end;
         }
         end = n;
@@ -294,19 +321,19 @@ AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, ui
     uint64_t L2 = 0;
     int sp = int(phase) - 7;                               // e = 22 - phase at the start (cabac_code.h:30 shifted onto the digit grid)
     uint32_t j = 0;                                        // digits produced
-    auto bin = [&](uint32_t c) {
-        const CodeEntry e = codes[c];
+    auto bin_e = [&](const CodeEntry &e) {
         const uint32_t rl = (e.row >> ((R >> 3) & 24)) & 0xffu;
         const uint32_t rm = R - rl;
         const uint32_t shm = ((rm >> 8) & 1u) ^ 1u;
         const uint32_t shl = uint32_t(clz32(rl)) - 23;
         const bool sym = e.meta & 1u, byp = e.meta >> 8;
         const uint32_t v = byp ? R : 2 * rm;               // what a 1 adds to low, in half units
-        const uint32_t sh = (sym ? shl : shm) + (e.meta >> 8);
+        const uint32_t sh0 = sym ? shl : shm, sh = sh0 + (e.meta >> 8);
         L2 = (L2 + ((e.meta & 2u) ? v : 0u)) << sh;
-        R = sym ? rl << shl : rm << shm;
+        R = (sym ? rl : rm) << sh0;
         sp += int(sh);
     };
+    auto bin = [&](uint32_t c) { bin_e(codes[c]); };
     auto digits = [&]() {                                  // every digit that is due, oldest (topmost) first
         while (sp >= 15) {
             const uint32_t d = uint32_t(L2 >> (sp + 1));
@@ -321,16 +348,18 @@ AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, ui
         const uint32_t head_end = ((from + 63) & ~63u) < to ? ((from + 63) & ~63u) : to;
         for_codes(res, from, head_end, [&](uint32_t, uint32_t c) { bin(c); digits(); return false; });
         uint32_t base = head_end;
-        for (; base + 64 <= to; base += 64) {              // a whole cache line per lane per trip (see for_codes_all)
-            const U4 *p = reinterpret_cast<const U4 *>(res + base);
-            const U4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+        if (base + 64 <= to) { const U4 *p = reinterpret_cast<const U4 *>(res + base); v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3]; }
+        for (; base + 64 <= to; base += 64) {              // a whole cache line per lane per trip, the next one in flight
             const uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+            if (base + 128 <= to) { const U4 *q = reinterpret_cast<const U4 *>(res + base + 64); v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 4
 #endif
             for (uint32_t k = 0; k < 16; k++) {
-                const uint32_t d = w[k];
-                bin(d & 0xffu); bin((d >> 8) & 0xffu); bin((d >> 16) & 0xffu); bin(d >> 24);
+                CodeEntry e[4];
+                code_entries4(codes, w[k], e);
+                bin_e(e[0]); bin_e(e[1]); bin_e(e[2]); bin_e(e[3]);
                 digits();                                  // 4 bins shift by at most 28: sp <= 14 + 28, L2 < 2^61
             }
         }
