@@ -163,9 +163,11 @@ AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g,
             g4(d);                                         // four codes, first in the low byte
         }
     };
-    const uint32_t head_end = ((from + 63) & ~63u) < to ? ((from + 63) & ~63u) : to;
+    // code by code up to a 16-byte boundary, 16-byte groups up to a cache line, then lines, and back down
+    const uint32_t head_end = ((from + 15) & ~15u) < to ? ((from + 15) & ~15u) : to;
     for_codes(res, from, head_end, [&](uint32_t, uint32_t c) { g(c); return false; });
     uint32_t base = head_end;
+    for (; (base & 63) && base + 16 <= to; base += 16) group16(*reinterpret_cast<const U4 *>(res + base));
     if (base + 64 <= to) {                                 // the next line is in flight while this one is worked on
         const U4 *p = reinterpret_cast<const U4 *>(res + base);
         U4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
@@ -176,6 +178,7 @@ AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g,
             v0 = n0; v1 = n1; v2 = n2; v3 = n3;
         }
     }
+    for (; base + 16 <= to; base += 16) group16(*reinterpret_cast<const U4 *>(res + base));
     if (base < to) for_codes(res, base, to, [&](uint32_t, uint32_t c) { g(c); return false; });
 }
 
@@ -345,9 +348,18 @@ AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, ui
     };
     const uint32_t to = st.end;
     if (from < to) {
-        const uint32_t head_end = ((from + 63) & ~63u) < to ? ((from + 63) & ~63u) : to;
+        auto four = [&](uint32_t d) {                      // 4 bins shift by at most 28: sp <= 14 + 28, L2 < 2^61
+            CodeEntry e[4];
+            code_entries4(codes, d, e);
+            bin_e(e[0]); bin_e(e[1]); bin_e(e[2]); bin_e(e[3]);
+            digits();
+        };
+        auto group16 = [&](const U4 &v) { four(v.x); four(v.y); four(v.z); four(v.w); };
+        // code by code up to a 16-byte boundary, 16-byte groups up to a cache line, then lines, and back down
+        const uint32_t head_end = ((from + 15) & ~15u) < to ? ((from + 15) & ~15u) : to;
         for_codes(res, from, head_end, [&](uint32_t, uint32_t c) { bin(c); digits(); return false; });
         uint32_t base = head_end;
+        for (; (base & 63) && base + 16 <= to; base += 16) group16(*reinterpret_cast<const U4 *>(res + base));
         U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
         if (base + 64 <= to) { const U4 *p = reinterpret_cast<const U4 *>(res + base); v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3]; }
         for (; base + 64 <= to; base += 64) {              // a whole cache line per lane per trip, the next one in flight
@@ -356,13 +368,9 @@ AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, ui
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 4
 #endif
-            for (uint32_t k = 0; k < 16; k++) {
-                CodeEntry e[4];
-                code_entries4(codes, w[k], e);
-                bin_e(e[0]); bin_e(e[1]); bin_e(e[2]); bin_e(e[3]);
-                digits();                                  // 4 bins shift by at most 28: sp <= 14 + 28, L2 < 2^61
-            }
+            for (uint32_t k = 0; k < 16; k++) four(w[k]);
         }
+        for (; base + 16 <= to; base += 16) group16(*reinterpret_cast<const U4 *>(res + base));
         if (base < to) for_codes(res, base, to, [&](uint32_t, uint32_t c) { bin(c); digits(); return false; });
     }
     // what is left is the coder's window: the top of digit g0 + j (with any carry) and 15 - e bits of the next
