@@ -214,12 +214,16 @@ AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const Cod
         for (uint32_t q = 0; q < 4; q++) { uint32_t sh; R[q] = post_lps_range(row, q, &sh); }
         i = f + 1;
     }
-    // until the four candidates have merged (a few bins)
+    // Until the four candidates have merged.  That takes a while -- on config 2 a mean of 66 bins, and the
+    // slowest of a wave's 64 lanes needs about 240 -- so the part of it that lies inside the chunk, where
+    // no bin can close the stretch, is walked 16 codes per load like the merged part.
     bool closed = false;
-    if (i < n) {
-        uint32_t i_next = n;
-        for_codes(res, i, n, [&](uint32_t idx, uint32_t c) {
-            if (R[0] == R[1] && R[1] == R[2] && R[2] == R[3]) { i_next = idx; return true; }
+    auto merged = [&]() { return R[0] == R[1] && R[1] == R[2] && R[2] == R[3]; };
+    auto code_by_code = [&](uint32_t stop) {               // up to `stop`, or merged, or closed
+        if (i >= stop) return;
+        uint32_t i_next = stop;
+        for_codes(res, i, stop, [&](uint32_t idx, uint32_t c) {
+            if (merged()) { i_next = idx; return true; }
             const bool closing = idx >= limit && code_is_boundary(c);
             if (closing)
                 for (uint32_t q = 0; q < 4; q++) o->exit_q |= uint8_t(((R[q] >> 6) & 3) << (2 * q));
@@ -230,6 +234,26 @@ AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const Cod
             return false;
         });
         i = i_next;
+    };
+    {
+        const uint32_t interior_end = limit < n ? limit : n;
+        const uint32_t a16 = (i + 15) & ~15u;
+        code_by_code(a16 < interior_end ? a16 : interior_end);
+        while (!merged() && i + 16 <= interior_end) {      // i is a multiple of 16 here
+            const U4 v = *reinterpret_cast<const U4 *>(res + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+            for (uint32_t k = 0; k < 4; k++) {
+                CodeEntry e[4];
+                code_entries4(codes, w[k], e);
+                for (uint32_t b = 0; b < 4; b++)
+                    for (uint32_t q = 0; q < 4; q++) T[q] += step_range(e[b], &R[q]);
+            }
+            i += 16;
+        }
+        code_by_code(n);
     }
     // merged: one range, 16 codes per load.  Below `limit` no bin can close the stretch.
     uint32_t Rm = R[0], Tm = 0, end = i;
