@@ -128,9 +128,9 @@ __global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, uint32_t *hist, uint3
 // form spent 75 % of its wave cycles stalled on issuing those stores).
 constexpr uint32_t kQuarter = kSortBlock / 4, kQuarterBatches = kQuarter / 64;
 
+template <uint32_t KEY_BITS>
 __global__ __launch_bounds__(256, 8) void k_k1p_scatter(Plan p, const int32_t *status, const uint32_t *boff,
-                                                     const uint32_t *run_start, uint8_t *sorted, uint32_t *qoff,
-                                                     uint32_t key_bits) {
+                                                     const uint32_t *run_start, uint8_t *sorted, uint32_t *qoff) {
     // LDS (dynamic, sized by the number of contexts so that more blocks fit a CU):
     extern __shared__ uint32_t scatter_lds[];
     const uint32_t nk = p.n_states, nk_pad = (nk + 63) & ~63u;
@@ -201,15 +201,23 @@ __global__ __launch_bounds__(256, 8) void k_k1p_scatter(Plan p, const int32_t *s
     const uint64_t lt = (uint64_t(1) << lane) - 1;
 #pragma unroll
     for (uint32_t j = 0; j < kQuarterBatches; j++) {
-        const uint32_t rec = recs[j];
+        uint32_t rec = recs[j];
+        asm volatile("" : "+v"(rec));                            // keeps this batch's ballots here: hoisted to the top, the 16 x KEY_BITS
+                                                                 // lane masks outlive the SGPR file and are spilled (measured 1.45x slower)
         const uint32_t sel = (rec >> 1) & 0x7ffu;
         const bool is_ctx = sel < nk;
-        uint64_t mask = __ballot(is_ctx);
-        for (uint32_t bit = 0; bit < key_bits; bit++) {
-            const bool one = (sel >> bit) & 1;
-            const uint64_t m = __ballot(one);
-            mask &= one ? m : ~m;
+        // lanes holding the same context: for every key bit keep the lanes whose bit equals mine,
+        // mask &= ~(ballot(bit) ^ (my bit ? ~0 : 0)), one three-input bit operation per half
+        const uint64_t m0 = __ballot(is_ctx);
+        uint32_t mask_lo = uint32_t(m0), mask_hi = uint32_t(m0 >> 32);
+#pragma unroll
+        for (uint32_t bit = 0; bit < KEY_BITS; bit++) {
+            const uint32_t mine = uint32_t(int32_t(sel << (31 - bit)) >> 31);
+            const uint64_t m = __ballot(mine != 0);
+            mask_lo &= ~(uint32_t(m) ^ mine);
+            mask_hi &= ~(uint32_t(m >> 32) ^ mine);
         }
+        const uint64_t mask = uint64_t(mask_lo) | uint64_t(mask_hi) << 32;
         if (is_ctx) {
             const uint32_t rank = __popcll(mask & lt);
             const uint32_t start = my_cnt[sel];
@@ -419,11 +427,17 @@ __global__ __launch_bounds__(256) void k_k1p_chain(Plan p, uint32_t total_chunks
         v = U4{w[0], w[1], w[2], w[3]};
     };
     uint32_t at = from;                                          // a multiple of kChunk; `sorted` is padded past rs[nk]
-    for (; at + 64 <= to; at += 64) {                            // a whole cache line per lane per trip
+    if (at + 64 <= to) {                                         // a whole cache line per lane per trip, the next one in flight
         U4 *q = reinterpret_cast<U4 *>(so + at);
         U4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
-        group16(v0, at); group16(v1, at + 16); group16(v2, at + 32); group16(v3, at + 48);
-        q[0] = v0; q[1] = v1; q[2] = v2; q[3] = v3;
+        for (; at + 64 <= to; at += 64) {
+            q = reinterpret_cast<U4 *>(so + at);
+            U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
+            if (at + 128 <= to) { n0 = q[4]; n1 = q[5]; n2 = q[6]; n3 = q[7]; }
+            group16(v0, at); group16(v1, at + 16); group16(v2, at + 32); group16(v3, at + 48);
+            q[0] = v0; q[1] = v1; q[2] = v2; q[3] = v3;
+            v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+        }
     }
     for (; at < to; at += 16) {
         U4 *q = reinterpret_cast<U4 *>(so + at);
@@ -769,8 +783,11 @@ static hipError_t launch_resolve(hipStream_t s, const Plan &p, uint32_t n_slices
     if (n_states > 0) {
         hipLaunchKernelGGL(k_k1p_scan, dim3(n_slices), dim3(1024), 0, s, p, hist, run_start);
         const uint32_t scatter_lds = 20 * ((n_states + 63) & ~63u) + 3 * kSortBlock;
-        hipLaunchKernelGGL(k_k1p_scatter, dim3(pl->total_blocks), dim3(256), scatter_lds, s, p, status, hist, run_start, sorted,
-                           qoff, key_bits);
+        auto scatter = key_bits <= 1 ? k_k1p_scatter<1> : key_bits == 2 ? k_k1p_scatter<2> : key_bits == 3 ? k_k1p_scatter<3> :
+                       key_bits == 4 ? k_k1p_scatter<4> : key_bits == 5 ? k_k1p_scatter<5> : key_bits == 6 ? k_k1p_scatter<6> :
+                       key_bits == 7 ? k_k1p_scatter<7> : key_bits == 8 ? k_k1p_scatter<8> : key_bits == 9 ? k_k1p_scatter<9> :
+                                                                                               k_k1p_scatter<10>;
+        hipLaunchKernelGGL(scatter, dim3(pl->total_blocks), dim3(256), scatter_lds, s, p, status, hist, run_start, sorted, qoff);
         hipLaunchKernelGGL(k_k1p_spec, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
                            sorted, seg);
         hipLaunchKernelGGL(k_k1p_link, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
