@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 8) void k_k1p_scatter(Plan p, const int32_t *s
         uint32_t mask_lo = uint32_t(m0), mask_hi = uint32_t(m0 >> 32);
 #pragma unroll
         for (uint32_t bit = 0; bit < KEY_BITS; bit++) {
-            const uint32_t mine = uint32_t(int32_t(sel << (31 - bit)) >> 31);
+            const uint32_t mine = uint32_t(__builtin_amdgcn_sbfe(int32_t(rec), bit + 1, 1));   // bit of the selector, as 0 / ~0
             const uint64_t m = __ballot(mine != 0);
             mask_lo &= ~(uint32_t(m) ^ mine);
             mask_hi &= ~(uint32_t(m >> 32) ^ mine);
@@ -375,7 +375,20 @@ __global__ __launch_bounds__(256) void k_k1p_chain(Plan p, uint32_t total_chunks
                                                    uint8_t *sorted, const Seg *seg, const uint8_t *entry,
                                                    uint8_t *final_states) {
     __shared__ uint32_t next[128];
-    if (threadIdx.x < 128) next[threadIdx.x] = d_tables.packed[threadIdx.x][1];
+    // two bins per look-up: pair[st] = { state after a first bin 0 | 1,  state after bins 00 | 01 | 10 | 11
+    // (first bin in the higher index bit) }: the walk is a chain of dependent LDS reads, this halves it
+    __shared__ uint2 pair[128];
+    if (threadIdx.x < 128) {
+        const uint32_t st = threadIdx.x, nx = d_tables.packed[st][1];
+        next[st] = nx;
+        uint32_t mid[2], end = 0;
+        for (uint32_t b0 = 0; b0 < 2; b0++) {
+            mid[b0] = ((b0 ^ st) & 1) ? (nx >> 8) : (nx & 0xffu);
+            const uint32_t n2 = d_tables.packed[mid[b0]][1];
+            for (uint32_t b1 = 0; b1 < 2; b1++) end |= (((b1 ^ mid[b0]) & 1) ? (n2 >> 8) : (n2 & 0xffu)) << (8 * (2 * b0 + b1));
+        }
+        pair[st] = make_uint2(mid[0] | mid[1] << 8, end);
+    }
     __syncthreads();
     const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
     if (gc >= total_chunks) return;
@@ -409,11 +422,13 @@ __global__ __launch_bounds__(256) void k_k1p_chain(Plan p, uint32_t total_chunks
         uint32_t w[4] = {v.x, v.y, v.z, v.w};
         if (at + 16 <= run_end && at + 16 <= to) {               // no run ends inside
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const uint32_t sh = (j & 3) * 8, bin = (w[j >> 2] >> sh) & 1u;
-                const uint32_t code = code_context(st, bin);
-                st = chain_next(next, st, bin);
-                w[j >> 2] = (w[j >> 2] & ~(0xffu << sh)) | (code << sh);
+            for (int j = 0; j < 16; j += 2) {
+                const uint32_t sh = (j & 3) * 8, d = w[j >> 2] >> sh, b0 = d & 1u, b1 = (d >> 8) & 1u;
+                const uint2 e = pair[st];
+                const uint32_t mid = (e.x >> (8 * b0)) & 0xffu;
+                const uint32_t c0 = code_context(st, b0), c1 = code_context(mid, b1);
+                st = (e.y >> (8 * (2 * b0 + b1))) & 0xffu;
+                w[j >> 2] = (w[j >> 2] & ~(0xffffu << sh)) | ((c0 | c1 << 8) << sh);
             }
         } else {
             for (uint32_t j = 0; j < 16 && at + j < to; j++) {
