@@ -61,6 +61,28 @@ def test_chunked_random_and_declined_slices(avr, oracle):
     assert status[-1] == avr.SLICE_BAD_RECORD
 
 
+@pytest.mark.parametrize("n_ctx", [1, 2, 3, 5, 17, 200, 513, 1024])
+def test_chunked_every_context_count_and_length_class(avr, oracle, n_ctx):
+    """The sort's key width, the LDS state tables and the per-chunk entry rows all depend on the number
+    of contexts; slice lengths sit on and around the chunk (1024) and sort-block (4096) boundaries."""
+    rng = np.random.default_rng(1000 + n_ctx)
+    lengths = [1, 15, 16, 17, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 12288, 20001]
+    slices = []
+    for i, n in enumerate(lengths):
+        recs, st = oracle_lib.random_cabac_stream(rng, n, n_ctx, p_bypass=0.15 if i % 2 else 0.0, terminate=bool(i % 3))
+        if i % 4 == 0:
+            st[:] = rng.integers(0, 128, n_ctx)             # includes pStateIdx 63
+        slices.append((recs, st))
+    w = avr.DeviceWorkload.from_host(0, [r for r, _ in slices], [s for _, s in slices], 0)
+    w.encode_chunked()
+    got, status = w.results()
+    fs = w.final_states.cpu().numpy().reshape(len(slices), -1)
+    for i, (r, s) in enumerate(slices):
+        want = oracle.cabac_encode(r, s)
+        assert status[i] == 0 and got[i] == want[0], f"slice {i} n={len(r)}"
+        assert fs[i][:n_ctx].tobytes() == want[1], f"final states of slice {i}"
+
+
 def test_chunked_full_size_config2_sampled(avr, oracle):
     w = avr.DeviceWorkload.synth(2, 512, 0, 0, 1000)
     w.encode_chunked()
