@@ -5,15 +5,12 @@
 // Differences in form, none in the bytes produced:
 //   * no callback: the caller evaluates probability_of_1(range) and updates low/range
 //     itself (the reference takes a std::function, arithmetic_code.h:106);
-//   * no `overflow` vector (arithmetic_code.h:154-174,200).  A digit that a later carry
-//     can still change is held as `pend` followed by a run of `nff` all-ones digits -- by
-//     construction the only shapes the reference's deferred digits can take: the first
-//     deferred digit is < all-ones, every digit deferred while the interval still
-//     straddles fixed_one is all-ones, and a deferral that starts below fixed_one makes
-//     everything before it final.  Output is therefore strictly append-only, which is
-//     what lets a lane stream bytes to HBM without ever reading them back;
-//   * the common case -- nothing held back, no carry, digit unambiguous -- is one compare
-//     and an append; everything else goes through the (rare) general path;
+//   * no `overflow` vector (arithmetic_code.h:154-174,200): digits are written through and a
+//     carry is added into the bytes already produced (see CabacEncoder).  An earlier form held a
+//     digit back together with a count of all-ones digits behind it -- the only shapes the
+//     reference's deferred digits can take -- which kept the output append-only but cost a
+//     certainty test per digit; measured slower on both kernels (config 5: K1 2.84 -> 2.70 ms,
+//     K2 3.51 -> 3.00 ms);
 //   * FixedPoint arithmetic is done in exactly the reference's width (uint32_t for the
 //     CABAC instantiation, cabac_code.h:18-24; uint64_t for recoded_code,
 //     recode.cpp:322-323) so wrap-around in finish() matches (arithmetic_code.h:131-137).
@@ -60,74 +57,6 @@ struct ByteWriter {
     }
 };
 
-template <typename F, int FBITS, int DBITS>
-struct RangeEncoder {
-    static constexpr F kOne = F(1) << (FBITS - 1);              // fixed_one, arithmetic_code.h:54-55
-    static constexpr uint32_t kDigitMask = (1u << DBITS) - 1;
-    static constexpr int kShift = FBITS - 1 - DBITS;            // log2(most_significant_digit), :150
-
-    F low, range;
-    int32_t pend;           // held-back digit (may still take a carry), -1 = none
-    uint32_t nff;           // all-ones digits held back behind it
-    ByteWriter w;
-
-    __device__ __forceinline__ void init(F initial_range, uint8_t *out, uint32_t cap) {
-        low = 0; range = initial_range; pend = -1; nff = 0;     // arithmetic_code.h:98-99
-        w.init(out, cap);
-    }
-
-    __device__ __forceinline__ void put_digit(uint32_t d) {
-        if (DBITS == 16) w.put16_even(d); else w.put8(d);
-    }
-
-    // Release everything held back, with (carry = 1) or without the pending carry.
-    __device__ void release(uint32_t carry) {
-        put_digit(uint32_t(pend) + carry);
-        const uint32_t fill = carry ? 0u : kDigitMask;
-        while (nff) { put_digit(fill); nff--; }
-        pend = -1;
-    }
-
-    // renormalize_and_emit_digit<CompressedDigit> (arithmetic_code.h:147-180)
-    __device__ __forceinline__ void emit_digit() {
-        const uint32_t carry = low >= kOne;                                         // :154
-        const uint32_t digit = uint32_t(low >> kShift) & kDigitMask;                // :158,164
-        const uint32_t top = uint32_t(F(low + F(range - 1)) >> kShift) & kDigitMask;   // :165
-        const bool certain = digit == top;
-        if (__builtin_expect(certain && pend < 0 && !carry, 1)) {
-            put_digit(digit);                                                       // :173
-        } else {
-            // still straddling fixed_one: one more all-ones digit behind the held-back one
-            const bool extend = !certain && !carry && pend >= 0 && digit == kDigitMask;
-            if (pend >= 0 && !extend) release(carry);                               // :155-157, :169-172
-            if (certain) put_digit(digit);
-            else if (extend) nff++;
-            else pend = int32_t(digit);                                             // :166-167
-        }
-        low = F(F(low & ((F(1) << kShift) - 1)) << DBITS);                          // :158,177-178
-        range = F(range << DBITS);                                                  // :179
-    }
-
-    // finish() (arithmetic_code.h:128-144): stop bit, then OutputDigit-sized (8-bit) digits.
-    __device__ void finish() {
-        for (F stop = kOne >> 1; stop > 0; stop >>= 1) {        // :131-137
-            const F x = F((low | stop) & F(~F(stop - 1)));
-            if (stop < range && low <= x && x < F(low + range)) { low = x; break; }
-        }
-        constexpr int sh8 = FBITS - 1 - 8;
-        while (low != 0) {                                      // :139-142 (range = 1: never deferred)
-            const uint32_t carry = low >= kOne;
-            if (carry) low -= kOne;
-            if (pend >= 0) release(carry);
-            const uint32_t digit = uint32_t(low >> sh8);
-            w.put8(digit);
-            low = F(F(low - (F(digit) << sh8)) << 8);
-        }
-        range = 0;                                              // :143
-        pend = -1; nff = 0;      // digits still held back are dropped, as the reference drops `overflow`
-    }
-};
-
 // The CABAC instantiation (arithmetic_code<uint32_t, uint16_t, 0x200>, cabac_code.h:18-24) in
 // WRITE-THROUGH form, used by k_cabac_encode.  Every digit is appended as soon as it exists; when low
 // crosses fixed_one the carry (arithmetic_code.h:154-157) is added into the bytes already produced,
@@ -135,9 +64,8 @@ struct RangeEncoder {
 // bytes in HBM, which nobody else touches.  The bytes are the same as with deferral (that is what the
 // reference's deferred digits plus the carry add up to); what changes is the cost of the common
 // case: no certainty test and no held-back state, and since one of a wave's 64 lanes emits on most
-// bins, the length of this path is paid per bin.  (Measured on config 5: held-back form 2.84 ms; this
-// form with a 2-byte store per digit 3.63 ms -- 64 partial-line stores per instruction -- hence the
-// staging word.)
+// bins, the length of this path is paid per bin.  (With a 2-byte store per digit instead of the
+// staging word: 3.63 ms on config 5 -- 64 partial-line stores per instruction.)
 struct CabacEncoder {
     static constexpr uint32_t kOne = 0x80000000u;       // fixed_one, arithmetic_code.h:54-55
     uint32_t low, range;
@@ -183,6 +111,54 @@ struct CabacEncoder {
             low = (low - (digit << 23)) << 8;
         }
         range = 0;                                                                      // :143
+    }
+};
+
+// The recoded instantiation (arithmetic_code<uint64_t, uint8_t>, recode.cpp:322-323) in the same
+// write-through form, used by k_range_encode: 8-bit digits, min_range 2^51 (arithmetic_code.h:61-62).
+struct RangeEncoder64 {
+    static constexpr uint64_t kOne = uint64_t(1) << 63; // fixed_one
+    uint64_t low, range;
+    ByteWriter w;
+
+    __device__ __forceinline__ void init(uint64_t initial_range, uint8_t *out, uint32_t capacity) {
+        low = 0; range = initial_range;
+        w.init(out, capacity);
+    }
+    __device__ void carry_back() {                      // as CabacEncoder::carry_back
+        const uint32_t r = w.n & 7;
+        if (r) {
+            const uint64_t mask = (uint64_t(1) << (8 * r)) - 1, v = (w.acc & mask) + 1;
+            w.acc = (w.acc & ~mask) | (v & mask);
+            if ((v >> (8 * r)) == 0) return;
+        }
+        uint32_t p = w.n - r;
+        if (p > w.cap) return;
+        while (p > 0) {
+            p--;
+            const uint32_t b = uint32_t(w.base[p]) + 1u;
+            w.base[p] = uint8_t(b);
+            if (b <= 0xffu) break;
+        }
+    }
+    __device__ __forceinline__ void emit_digit() {      // arithmetic_code.h:147-180 with 8-bit digits
+        if (__builtin_expect(low >= kOne, 0)) { carry_back(); low -= kOne; }
+        w.put8(uint32_t(low >> 55));
+        low = (low & ((uint64_t(1) << 55) - 1)) << 8;
+        range <<= 8;
+    }
+    __device__ void finish() {                          // arithmetic_code.h:128-144
+        for (uint64_t stop = kOne >> 1; stop > 0; stop >>= 1) {
+            const uint64_t x = (low | stop) & ~(stop - 1);
+            if (stop < range && low <= x && x < uint64_t(low + range)) { low = x; break; }
+        }
+        while (low != 0) {
+            if (low >= kOne) { carry_back(); low -= kOne; }
+            const uint32_t digit = uint32_t(low >> 55);
+            w.put8(digit);
+            low = (low - (uint64_t(digit) << 55)) << 8;
+        }
+        range = 0;
     }
 };
 

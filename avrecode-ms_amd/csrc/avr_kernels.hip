@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void k_range_encode(
     const bool active = st == AVR_SLICE_OK;
     const uint32_t nb = active ? n_bins[slice] : 0;
 
-    RangeEncoder<uint64_t, 64, 8> e;
+    RangeEncoder64 e;
     const uint64_t o0 = out_off[slice];
     const uint32_t cap = uint32_t(out_off[slice + 1] - o0);
     e.init(uint64_t(1) << 63, out + o0, cap);                    // arithmetic_code.h:96-97
