@@ -147,10 +147,13 @@ __global__ __launch_bounds__(256, 8) void k_k1p_scatter(Plan p, const int32_t *s
     // this wave's records: batch j of the quarter is r[q0 + 64 j + lane]
     const uint32_t q0 = i0 + w * kQuarter;
     uint32_t recs[kQuarterBatches];
+    const uint16_t *rq = r + q0 + lane;
+    if (q0 + kQuarter <= i1) {                                   // a whole quarter (all but a slice's last block): no bounds to check
 #pragma unroll
-    for (uint32_t j = 0; j < kQuarterBatches; j++) {
-        const uint32_t i = q0 + 64 * j + lane;
-        recs[j] = i < i1 ? r[i] : uint32_t(AVR_NOP_CABAC);
+        for (uint32_t j = 0; j < kQuarterBatches; j++) recs[j] = rq[64 * j];
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < kQuarterBatches; j++) recs[j] = q0 + 64 * j + lane < i1 ? rq[64 * j] : uint32_t(AVR_NOP_CABAC);
     }
     for (uint32_t k = t; k < 4 * nk_pad; k += 256) cnt[k] = 0;
     __syncthreads();
@@ -192,9 +195,10 @@ __global__ __launch_bounds__(256, 8) void k_k1p_scatter(Plan p, const int32_t *s
     }
     __syncthreads();
     // where every quarter's bins of every context start in the slice's sorted order (for k_k1p_replay)
-    for (uint32_t e = t; e < 4 * nk; e += 256) {
-        const uint32_t q = e / nk, k = e - q * nk;
-        qoff[(size_t(b) * 4 + q) * nk + k] = cnt[q * nk_pad + k] + delta[k];
+    for (uint32_t k = t; k < nk; k += 256) {
+        const uint32_t d = delta[k];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) qoff[(size_t(b) * 4 + q) * nk + k] = cnt[q * nk_pad + k] + d;
     }
     __syncthreads();
     uint32_t *my_cnt = cnt + w * nk_pad;
