@@ -93,8 +93,17 @@ __global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, uint32_t *hist, uint3
     const uint32_t s = blockIdx.x, k = threadIdx.x, nk = p.n_states;
     const uint32_t b0 = p.blk_base[s], b1 = p.blk_base[s + 1];
     uint32_t total = 0;
-    if (k < nk)
-        for (uint32_t b = b0; b < b1; b++) total += hist[size_t(b) * nk + k];
+    if (k < nk) {
+        uint32_t b = b0;
+        for (; b + 8 <= b1; b += 8) {                            // eight loads in flight: the loop is their latency
+            uint32_t c[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) c[j] = hist[size_t(b + j) * nk + k];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) total += c[j];
+        }
+        for (; b < b1; b++) total += hist[size_t(b) * nk + k];
+    }
     sc[k] = total;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {                    // inclusive scan over contexts
@@ -106,7 +115,15 @@ __global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, uint32_t *hist, uint3
     uint32_t run = sc[k] - total;                                // exclusive
     if (k < nk) {
         run_start[size_t(s) * (nk + 1) + k] = run;
-        for (uint32_t b = b0; b < b1; b++) {
+        uint32_t b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            uint32_t c[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) c[j] = hist[size_t(b + j) * nk + k];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) { hist[size_t(b + j) * nk + k] = run; run += c[j]; }
+        }
+        for (; b < b1; b++) {
             const uint32_t c = hist[size_t(b) * nk + k];
             hist[size_t(b) * nk + k] = run;
             run += c;
