@@ -645,8 +645,10 @@ __global__ __launch_bounds__(256) void k_k1p_b2(Plan p, const int32_t *status, c
                                                 SliceTotals *tot) {
     __shared__ Stretch tile[kB2Tile];
     __shared__ Entry ent[kB2Tile];
+    __shared__ uint8_t xq[kB2Tile], qin[kB2Tile];               // exit quarter per entry quarter (2 bits each); entry quarter
+    __shared__ uint32_t wsum[4];
     __shared__ uint32_t carry[4];                                // T, q, r, bad across tiles
-    const uint32_t s = blockIdx.x, t = threadIdx.x;
+    const uint32_t s = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (status[s] != AVR_SLICE_OK) {
         if (t == 0) { tot[s].t_total = 0; tot[s].r_final = 510; tot[s].bad = 0; tot[s].pad = 0; }
         return;
@@ -659,20 +661,48 @@ __global__ __launch_bounds__(256) void k_k1p_b2(Plan p, const int32_t *status, c
         uint32_t *dst = reinterpret_cast<uint32_t *>(tile);
         for (uint32_t i = t; i < cnt * (sizeof(Stretch) / 4); i += 256) dst[i] = src[i];
         __syncthreads();
+        // the only serial part is the quarter: one byte look-up per stretch (an inactive chunk maps q to q)
+        for (uint32_t c = t; c < kB2Tile; c += 256) xq[c] = c < cnt && tile[c].first != kNone ? tile[c].exit_q : uint8_t(0xE4);
+        __syncthreads();
         if (t == 0) {
-            uint32_t T = carry[0], q = carry[1], r = carry[2], bad = carry[3];
-            for (uint32_t c = 0; c < cnt; c++) {
-                if (tile[c].first == kNone) continue;
-                ent[c].t_start = T;
-                ent[c].q = q;
-                T += tile[c].t_exit[q];
-                r = tile[c].r_exit[q];
-                bad |= tile[c].too_long;
-                q = (tile[c].exit_q >> (2 * q)) & 3;
-            }
-            carry[0] = T; carry[1] = q; carry[2] = r; carry[3] = bad;
+            uint32_t q = carry[1];
+            for (uint32_t c = 0; c < cnt; c++) { qin[c] = uint8_t(q); q = (xq[c] >> (2 * q)) & 3; }
+            carry[1] = q;
         }
         __syncthreads();
+        // everything else follows from the entry quarters: shifts (prefix sum), range, flags.  Thread t
+        // takes stretches 4t .. 4t+3 of the tile.
+        uint32_t tv[4], sum = 0, bad = 0, last = kNone;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t c = 4 * t + j;
+            const bool on = c < cnt && tile[c].first != kNone;
+            tv[j] = on ? tile[c].t_exit[qin[c]] : 0;
+            sum += tv[j];
+            if (on) { bad |= tile[c].too_long; last = c; }
+        }
+        uint32_t incl = sum;
+        for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+        if (lane == 63) wsum[w] = incl;
+        // the last active stretch of the tile gives the range; any too_long flags the slice
+        const uint64_t has = __ballot(last != kNone);
+        __syncthreads();
+        uint32_t run = carry[0] + incl - sum;
+        for (uint32_t v = 0; v < w; v++) run += wsum[v];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t c = 4 * t + j;
+            if (c < cnt) { ent[c].t_start = run; ent[c].q = qin[c]; }
+            run += tv[j];
+        }
+        if (bad) atomicOr(&carry[3], 1u);
+        __syncthreads();
+        if (t == 255) carry[0] = run;                            // total shifts so far
+        // range after the tile: the highest active stretch (waves in order, the last one that has any wins)
+        for (uint32_t v = 0; v < 4; v++) {
+            if (w == v && has && lane == 63 - uint32_t(__builtin_clzll(has))) carry[2] = tile[last].r_exit[qin[last]];
+            __syncthreads();
+        }
         uint32_t *eo = reinterpret_cast<uint32_t *>(en + c0 + base);
         const uint32_t *ei = reinterpret_cast<const uint32_t *>(ent);
         for (uint32_t i = t; i < cnt * (sizeof(Entry) / 4); i += 256) eo[i] = ei[i];

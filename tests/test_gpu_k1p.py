@@ -83,6 +83,18 @@ def test_chunked_every_context_count_and_length_class(avr, oracle, n_ctx):
         assert fs[i][:n_ctx].tobytes() == want[1], f"final states of slice {i}"
 
 
+def test_chunked_very_long_slices(avr, oracle):
+    """More than 1024 chunks per slice: the per-slice kernels (B2, D) go through several tiles."""
+    rng = np.random.default_rng(2024)
+    slices = [oracle_lib.random_cabac_stream(rng, n, 40) for n in (1_300_000, 2_100_001, 5)]
+    w = avr.DeviceWorkload.from_host(0, [r for r, _ in slices], [s for _, s in slices], 0)
+    w.encode_chunked()
+    got, status = w.results()
+    for i, (r, s) in enumerate(slices):
+        want = oracle.cabac_encode(r, s)
+        assert status[i] == 0 and got[i] == want[0], f"slice {i}"
+
+
 def test_chunked_full_size_config2_sampled(avr, oracle):
     w = avr.DeviceWorkload.synth(2, 512, 0, 0, 1000)
     w.encode_chunked()
