@@ -753,7 +753,8 @@ __global__ __launch_bounds__(256) void k_k1p_d(Plan p, const SliceTotals *tot, c
                                                uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
                                                int32_t *status) {
     __shared__ uint32_t dig[kTile];
-    __shared__ uint32_t seg_g[256], seg_p[256], seg_cin[256];
+    __shared__ uint32_t seg_g[256], seg_cin[256];
+    __shared__ uint64_t seg_gm[4], seg_pm[4];
     __shared__ uint32_t sh_carry;
     const uint32_t s = blockIdx.x, t = threadIdx.x;
     if (status[s] != AVR_SLICE_OK) { if (t == 0) out_len[s] = 0; return; }
@@ -791,27 +792,41 @@ __global__ __launch_bounds__(256) void k_k1p_d(Plan p, const SliceTotals *tot, c
             c = v >> 16;
             all_ones &= (v & 0xffffu) == 0xffffu;
         }
-        seg_g[t] = c;
-        seg_p[t] = all_ones;
+        // Carries run from segment 255 (the low-order end) down to segment 0.  Digit sums overlap where
+        // stretches meet, so they are small integers, not bits: segment k sends on what it made itself
+        // (c), plus one if it is all ones and receives anything.  WHETHER a segment receives anything
+        // is a carry chain over (generate = c > 0, propagate = all ones) -- solved for 64 segments at
+        // a time by one 64-bit addition of the two lane masks, bit-reversed so that it runs upward.
+        const bool gen = c > 0, prop = all_ones && !gen;
+        const uint64_t gm = __builtin_bitreverse64(__ballot(gen)), pm = __builtin_bitreverse64(__ballot(prop));
+        if ((t & 63) == 0) { seg_gm[t >> 6] = gm; seg_pm[t >> 6] = pm; }
         __syncthreads();
-        if (t == 0) {
-            uint32_t cin = carry_in;
-            for (uint32_t k = 256; k-- > 0;) {
-                seg_cin[k] = cin;
-                // digit sums overlap where stretches meet, so carries are small integers, not bits: a
-                // segment sends on what it made itself, plus one if it is all ones and receives any
-                cin = seg_g[k] + ((seg_p[k] && cin) ? 1u : 0u);
-            }
-            sh_carry = cin;                              // into the next (higher-order) tile
+        uint32_t into = carry_in > 0;                    // into segment 255, then into each wave's top segment
+        bool recv = false;
+        for (uint32_t v = 4; v-- > 0;) {
+            const uint64_t a = seg_gm[v] | seg_pm[v], b2 = seg_gm[v], sum = a + b2 + into;
+            if (v == (t >> 6)) recv = (__builtin_bitreverse64(sum ^ a ^ b2) >> (t & 63)) & 1;   // carry into my segment
+            into = uint32_t(((a & b2) | ((a | b2) & ~sum)) >> 63);
         }
+        seg_g[t] = c + ((all_ones && recv) ? 1u : 0u);   // what segment t sends to segment t - 1
         __syncthreads();
-        if (seg_cin[t]) {
+        // the tile's own carry-in goes to its last segment that has digits (a partial tile -- the
+        // highest-order one -- leaves the segments behind it empty; they only pass the chain on)
+        const uint32_t n_seg = (cnt + kSeg - 1) / kSeg;
+        seg_cin[t] = t + 1 >= n_seg ? carry_in : seg_g[t + 1];
+        if (t == 0) sh_carry = seg_g[0];                 // into the next (higher-order) tile
+        __syncthreads();
+        if (t < n_seg && seg_cin[t]) {
             uint32_t c2 = seg_cin[t];
             for (uint32_t i = b; i-- > a && c2;) {
                 const uint32_t v = dig[i] + c2;
                 dig[i] = v & 0xffffu;
                 c2 = v >> 16;
             }
+            // What was sent on assumed that only an all-ones segment overflows when it receives.  A
+            // carry of 2 or more into a segment of the shape ffff ... ffff fffe would too (it takes two
+            // overlapping windows and 33 particular digits); then the slice is handed to the serial kernel.
+            if (c2 != ((all_ones && recv) ? 1u : 0u)) status[s] = AVR_SLICE_RETRY_SERIAL;
         }
         __syncthreads();
         for (uint32_t i = t; i < cnt; i += 256) {
