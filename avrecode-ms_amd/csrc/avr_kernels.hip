@@ -67,7 +67,7 @@ struct CabacLane {
     uint32_t n_states;
     uint32_t scratch;       // byte offset of the lane's scratch dword
 
-    __device__ __forceinline__ bool bin(uint32_t rec, const uint2 *tab, uint8_t *st8) {
+    __device__ __forceinline__ void bin(uint32_t rec, const uint2 *tab, uint8_t *st8) {
         const uint32_t sel = (rec >> 1) & 0x7ffu;
         const bool is_ctx = sel < n_states;
         // state byte of (context, lane): dword (sel >> 2, lane), byte sel & 3
@@ -84,14 +84,14 @@ struct CabacLane {
         const int norm = 23 - __builtin_clz(e.range);
         const uint32_t q = (e.range >> (norm + 6)) & 3;          // (range_approx & 0x180) >> 7, :39-40
         const uint32_t r_tab = ((ent.x >> (q * 8)) & 0xffu) << norm;              // :40-41, :60
-        const uint32_t r1 = sel == AVR_SEL_BYPASS ? (e.range >> 1) : r_tab;       // :53
+        // bypass (:53): its table row is 0 and the top half of ent.y is all ones, so this is an OR, not a branch
+        const uint32_t r1 = r_tab | ((e.range >> 1) & uint32_t(int32_t(ent.y) >> 31));
         const uint32_t sym = (rec ^ s) & 1;                      // :34 (pseudo-states have valMPS 0)
         const uint32_t r0 = e.range - r1;                        // arithmetic_code.h:107-114
         e.low += sym ? r0 : 0u;
         e.range = sym ? r1 : r0;
-        st8[saddr] = uint8_t(sym ? (ent.y >> 8) : ent.y);        // cabac_code.h:43-47
+        st8[saddr] = uint8_t(ent.y >> (8 * sym));                // cabac_code.h:43-47
         if (e.range < 0x200u) e.emit_digit();                    // arithmetic_code.h:115-122 (one digit)
-        return rec == ((AVR_SEL_TERMINATE << 1) | 1);            // cabac_code.h:63-65
     }
 };
 
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
     const uint32_t g = blockIdx.x * 64 + lane;
     for (uint32_t i = lane; i < 128; i += 64)
         tab[i] = make_uint2(d_tables.packed[i][0], d_tables.packed[i][1]);
-    if (lane < 8)                                                // 130: terminate (LPS range 2), others 0
-        tab[128 + lane] = make_uint2(lane == 2 ? 0x02020202u : 0u, 0u);
+    if (lane < 8)                                                // 128: bypass (flagged in .y), 130: terminate (LPS range 2), others 0
+        tab[128 + lane] = make_uint2(lane == 2 ? 0x02020202u : 0u, lane == 0 ? 0xffff0000u : 0u);
 
     const bool in_range = g < n_slices;
     const uint32_t slice = in_range ? (order ? order[g] : g) : 0;
@@ -148,7 +148,11 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
     const uint4 nop4 = make_uint4(AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2);
     uint4 cur = n_chunks > 0 ? src.load(0) : nop4;
     uint4 nx1 = n_chunks > 1 ? src.load(1) : nop4;
-    uint32_t term_at = 0xffffffffu;                              // record index of put_terminate(1)
+    // put_terminate(1) (cabac_code.h:63-65) ends the slice: in a well-formed stream it is the last record,
+    // and what follows it in its 16-byte chunk is padding that changes nothing, so the bins are not
+    // tested one by one for it -- its position is only remembered (a bin after it flags the slice).
+    uint32_t term_at = 0xffffffffu;                              // record index of the first put_terminate(1)
+    constexpr uint32_t kTerm1 = (AVR_SEL_TERMINATE << 1) | 1;
     for (uint32_t c = 0; c < n_chunks && term_at == 0xffffffffu; c++) {
         const uint4 nx2 = (c + 2 < n_chunks) ? src.load(c + 2) : nop4;
         uint32_t w0 = cur.x, w1 = cur.y, w2 = cur.z, w3 = cur.w;
@@ -156,8 +160,11 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
         for (uint32_t k = 0; k < 4; k++) {
             const uint32_t d = w0;
             w0 = w1; w1 = w2; w2 = w3;
-            if (L.bin(d & 0xffffu, tab, st8)) { term_at = c * 8 + 2 * k; break; }
-            if (L.bin(d >> 16, tab, st8)) { term_at = c * 8 + 2 * k + 1; break; }
+            const uint32_t i = c * 8 + 2 * k;
+            L.bin(d & 0xffffu, tab, st8);
+            L.bin(d >> 16, tab, st8);
+            const uint32_t t0 = (d & 0xffffu) == kTerm1 ? i : (d >> 16) == kTerm1 ? i + 1 : 0xffffffffu;
+            term_at = term_at < t0 ? term_at : t0;
         }
         cur = nx1;
         nx1 = nx2;
