@@ -358,15 +358,15 @@ int avr_batch_run(avr_batch *b) {
         AVR_HIP(avr::launch_k1p(s, b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, n32, k_states, uint32_t(k_ns), &plan, wsp,
                                 b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p, k_final));
     } else {
-    AVR_HIP(avr::launch_pack_tiles(s, b->kind, uint32_t(k_ns), b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, b->d_order.p, n32,
-                                   b->d_tile_off.p, b->d_tiles.p, b->d_status.p));
-    AVR_HIP(hipEventRecord(b->ev[2], s));
-    if (cabac)
-        AVR_HIP(avr::launch_cabac_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, k_states,
-                                         uint32_t(k_ns), b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p, k_final));
-    else
-        AVR_HIP(avr::launch_range_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_out.p,
-                                         b->d_out_off.p, b->d_out_len.p, b->d_status.p));
+        AVR_HIP(avr::launch_pack_tiles(s, b->kind, uint32_t(k_ns), b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, b->d_order.p, n32,
+                                       b->d_tile_off.p, b->d_tiles.p, b->d_status.p));
+        AVR_HIP(hipEventRecord(b->ev[2], s));
+        if (cabac)
+            AVR_HIP(avr::launch_cabac_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, k_states,
+                                             uint32_t(k_ns), b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p, k_final));
+        else
+            AVR_HIP(avr::launch_range_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_out.p,
+                                             b->d_out_off.p, b->d_out_len.p, b->d_status.p));
     }
     if (b->n_dense) {        // final states back in the caller's numbering; untouched contexts keep their initial state
         AVR_HIP(hipMemcpyAsync(b->d_final.p, b->d_states.p, n * ns, hipMemcpyDeviceToDevice, s));
