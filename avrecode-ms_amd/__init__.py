@@ -89,6 +89,7 @@ SIGNATURES = {
     "avr_batch_reset": (c_int, [c_void_p]),
     "avr_batch_add_slice_cabac": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
     "avr_batch_add_slice_range": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "avr_batch_add_slice_codes": (c_int, [c_void_p, c_void_p, c_size_t]),
     "avr_batch_run": (c_int, [c_void_p]),
     "avr_batch_get": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
     "avr_batch_get_states": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]),
@@ -236,6 +237,12 @@ class Batch:
         import numpy as np
         r = np.ascontiguousarray(recs, dtype=np.uint16)
         return _check(self._L.avr_batch_add_slice_range(self._h, r.ctypes.data, r.size))
+
+    def add_codes(self, codes) -> int:
+        """K1 from resolved codes (one uint8 per bin: AVR_CODE_CONTEXT / _BYPASS / _TERMINATE)."""
+        import numpy as np
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        return _check(self._L.avr_batch_add_slice_codes(self._h, c.ctypes.data, c.size))
 
     def run(self):
         _check(self._L.avr_batch_run(self._h))

@@ -246,6 +246,76 @@ int avr_batch_add_slice_range(avr_batch *b, const uint16_t *recs, size_t n) {
     return add_slice(b, AVR_KIND_RANGE, recs, n, nullptr, 0);
 }
 
+// Resolved codes live in the same pinned buffer as records would, as bytes: slice i at byte
+// code_off[i] (the res_off of the chunk plan: 16-byte aligned, padded with a group of its own).
+int avr_batch_add_slice_codes(avr_batch *b, const uint8_t *codes, size_t n) {
+    if (!b) return fail(AVR_ERR_INVALID, "null batch");
+    if (!codes && n) return fail(AVR_ERR_INVALID, "null codes");
+    if (b->ran) return fail(AVR_ERR_INVALID, "batch already ran; call avr_batch_reset first");
+    if (b->kind >= 0 && b->kind != AVR_KIND_CABAC_CODES) return fail(AVR_ERR_INVALID, "a batch holds slices of one kind only");
+    if (n > 0xfffffff0u) return fail(AVR_ERR_INVALID, "slice too long");
+    if (b->n_bins.size() >= b->max_slices) return fail(AVR_ERR_CAPACITY, "batch holds max_slices=%zu slices", b->max_slices);
+    if (b->total_bins + n > b->max_bins) return fail(AVR_ERR_CAPACITY, "batch holds max_bins=%zu records", b->max_bins);
+    const uint64_t off = b->rec_off.back(), padded = ((uint64_t(n) + 15) & ~uint64_t(15)) + 16;
+    if (off + padded > (b->max_bins + 8 * b->max_slices) * sizeof(uint16_t))
+        return fail(AVR_ERR_CAPACITY, "batch code buffer full (%zu slices)", b->n_bins.size());
+    uint8_t *dst = reinterpret_cast<uint8_t *>(b->h_recs.p) + off;
+    if (n) memcpy(dst, codes, n);
+    memset(dst + n, AVR_CODE_BYPASS(0), padded - n);             // the padding value of a resolved stream (bypass 0, never coded)
+    b->total_bins += n;
+    b->rec_off.push_back(off + padded);
+    b->n_bins.push_back(uint32_t(n));
+    b->kind = AVR_KIND_CABAC_CODES;
+    return int(b->n_bins.size()) - 1;
+}
+
+static int fetch_output(avr_batch *b, const std::vector<uint64_t> &out_off, uint32_t n32);
+
+// A batch of resolved codes: H2D of one byte per bin, K1p phases B-D, D2H.
+static int run_codes(avr_batch *b, uint32_t n32) {
+    const size_t n = n32;
+    std::vector<uint64_t> out_off(n + 1, 0), dig_off(n + 1, 0);
+    std::vector<uint32_t> chunk_base(n + 1, 0), chunk_slice;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t nb = b->n_bins[i];
+        out_off[i + 1] = out_off[i] + ((nb + 16 + 7) & ~uint64_t(7));
+        dig_off[i + 1] = dig_off[i] + nb / 2 + 8;
+        const uint32_t nc = uint32_t(std::max<uint64_t>(1, (nb + AVR_CHUNK_BINS - 1) / AVR_CHUNK_BINS));
+        chunk_base[i + 1] = chunk_base[i] + nc;
+        chunk_slice.insert(chunk_slice.end(), nc, uint32_t(i));
+    }
+    const uint64_t total_codes = b->rec_off.back(), total_out = out_off.back();
+    int rc;
+    if ((rc = b->d_recs.reserve((total_codes + 64) / 2 + 1)) || (rc = b->d_res_off.reserve(n + 1)) || (rc = b->d_dig_off.reserve(n + 1)) ||
+        (rc = b->d_chunk_base.reserve(n + 1)) || (rc = b->d_chunk_slice.reserve(chunk_slice.size())) ||
+        (rc = b->d_out_off.reserve(n + 1)) || (rc = b->d_dense_off.reserve(n + 1)) || (rc = b->d_n_bins.reserve(n)) ||
+        (rc = b->d_out_len.reserve(n)) || (rc = b->d_status.reserve(n)) || (rc = b->d_out.reserve(total_out)) ||
+        (rc = b->h_out_len.reserve(n)) || (rc = b->h_status.reserve(n)))
+        return rc;
+    avr_chunk_plan plan{b->d_res_off.p, b->d_chunk_base.p, b->d_chunk_slice.p, nullptr, nullptr, b->d_dig_off.p,
+                        total_codes, dig_off.back(), chunk_base.back(), 0};
+    const size_t ws = avr::k1p_code_workspace_bytes(n, &plan);
+    if ((rc = b->d_workspace.reserve(ws + 256))) return rc;
+    hipStream_t s = b->stream;
+    AVR_HIP(hipEventRecord(b->ev[0], s));
+    AVR_HIP(hipMemcpyAsync(b->d_recs.p, b->h_recs.p, total_codes, hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_res_off.p, b->rec_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_dig_off.p, dig_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_chunk_base.p, chunk_base.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_chunk_slice.p, chunk_slice.data(), chunk_slice.size() * 4, hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_out_off.p, out_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemcpyAsync(b->d_n_bins.p, b->n_bins.data(), n * 4, hipMemcpyHostToDevice, s));
+    AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
+    AVR_HIP(hipStreamSynchronize(s));                            // the plan vectors are pageable locals
+    AVR_HIP(hipEventRecord(b->ev[1], s));
+    AVR_HIP(hipEventRecord(b->ev[2], s));
+    uint8_t *wsp = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(b->d_workspace.p) + 255) & ~uintptr_t(255));
+    AVR_HIP(avr::launch_k1p_code(s, reinterpret_cast<const uint8_t *>(b->d_recs.p), b->d_n_bins.p, n32, &plan, wsp, b->d_out.p,
+                                 b->d_out_off.p, b->d_out_len.p, b->d_status.p));
+    b->last_path = 1;
+    return fetch_output(b, out_off, n32);
+}
+
 int avr_batch_run(avr_batch *b) {
     if (!b) return fail(AVR_ERR_INVALID, "null batch");
     if (b->ran) return fail(AVR_ERR_INVALID, "batch already ran");
@@ -255,6 +325,7 @@ int avr_batch_run(avr_batch *b) {
     b->dense_off.assign(n + 1, 0);
     if (n == 0) return AVR_OK;
     const uint32_t n32 = uint32_t(n);
+    if (b->kind == AVR_KIND_CABAC_CODES) return run_codes(b, n32);
     const size_t ns = b->n_states;
     const bool cabac = b->kind == AVR_KIND_CABAC;
 
@@ -374,13 +445,20 @@ int avr_batch_run(avr_batch *b) {
             AVR_HIP(avr::launch_states_permute(s, b->d_final_dense.p, uint32_t(k_ns), b->d_final.p, uint32_t(ns), b->d_index.p,
                                                uint32_t(b->n_dense), n, 1));
     }
+    return fetch_output(b, out_off, n32);
+}
+
+// lengths, statuses and final states to the host; the coded bytes gathered densely on the device, then one D2H copy
+static int fetch_output(avr_batch *b, const std::vector<uint64_t> &out_off, uint32_t n32) {
+    const size_t n = n32, ns = b->n_states;
+    const bool with_states = b->kind == AVR_KIND_CABAC && ns;
+    hipStream_t s = b->stream;
+    int rc;
     AVR_HIP(hipEventRecord(b->ev[3], s));
     AVR_HIP(hipMemcpyAsync(b->h_out_len.p, b->d_out_len.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     AVR_HIP(hipMemcpyAsync(b->h_status.p, b->d_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (cabac && ns) AVR_HIP(hipMemcpyAsync(b->h_final.p, b->d_final.p, n * ns, hipMemcpyDeviceToHost, s));
+    if (with_states) AVR_HIP(hipMemcpyAsync(b->h_final.p, b->d_final.p, n * ns, hipMemcpyDeviceToHost, s));
     AVR_HIP(hipStreamSynchronize(s));
-
-    // gather the coded bytes densely on the device, then one D2H copy
     for (size_t i = 0; i < n; i++) {
         const uint64_t cap = out_off[i + 1] - out_off[i];
         b->dense_off[i + 1] = b->dense_off[i] + std::min<uint64_t>(b->h_out_len.p[i], cap);

@@ -202,6 +202,7 @@ class decompress_recorder {
         else symbol = decoder_.get(model_->probability_for_state(decoder_.range(), context));
         if (!seen_[context]) { seen_[context] = 1; init_states_[context] = *state; n_states_ = std::max(n_states_, context + 1); }
         recs_.push_back(uint16_t(symbol | (context << 1)));                             // cabac_encoder.put, deferred
+        codes_.push_back(uint8_t(AVR_CODE_CONTEXT(*state, symbol)));                    // the same call with *state resolved
         const CabacTables &t = cabac_bin_decoder::tables();                             // cabac_code.h:43-47
         *state = symbol != (*state & 1) ? t.mlps_state[127 - *state] : t.mlps_state[128 + *state];
         model_->update_state(symbol, context);                                          // :1454
@@ -211,12 +212,14 @@ class decompress_recorder {
         const int symbol = decoder_.get(model_->probability_for_state(decoder_.range(), kKeyBypass));
         model_->update_state(symbol, kKeyBypass);
         recs_.push_back(uint16_t(symbol | (AVR_SEL_BYPASS << 1)));
+        codes_.push_back(uint8_t(AVR_CODE_BYPASS(symbol)));
         return symbol;
     }
     int get_terminate() {                                                               // :1469-1481
         const int symbol = decoder_.get(model_->probability_for_state(decoder_.range(), kKeyTerminate));
         model_->update_state(symbol, kKeyTerminate);
         recs_.push_back(uint16_t(symbol | (AVR_SEL_TERMINATE << 1)));
+        codes_.push_back(uint8_t(AVR_CODE_TERMINATE(symbol)));
         if (symbol) finished_ = true;
         return symbol;
     }
@@ -231,6 +234,8 @@ class decompress_recorder {
     void end_coding_type(CodingType ct) { model_->end_coding_type(ct); }                // :1500-1505
     bool finished() const { return finished_; }
     const std::vector<uint16_t> &records() const { return recs_; }
+    // the same bins as resolved codes (AVR_CODE_*): what avr_batch_add_slice_codes takes; half the bytes, no state arrays
+    const std::vector<uint8_t> &codes() const { return codes_; }
     const uint8_t *init_states() const { return init_states_; }   // *state as it was at each context's first bin
     int n_states() const { return n_states_; }                     // highest context touched + 1
 
@@ -244,6 +249,7 @@ class decompress_recorder {
     range_decoder decoder_;
     const uint8_t *state_base_;
     std::vector<uint16_t> recs_;
+    std::vector<uint8_t> codes_;
     uint8_t seen_[AVR_MAX_STATES], init_states_[AVR_MAX_STATES];
     int n_states_ = 0;
     bool finished_ = false;

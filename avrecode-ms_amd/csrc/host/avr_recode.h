@@ -331,10 +331,7 @@ class decompressor {                                     // recode.cpp:1319-1598
                 throw std::runtime_error("Expected CABAC block.");
             }
         }
-        ~cabac_decoder() {
-            if (recorder_) d_->pending_.push_back({index_, recorder_->records(),
-                                                   std::vector<uint8_t>(recorder_->init_states(), recorder_->init_states() + AVR_MAX_STATES)});
-        }
+        ~cabac_decoder() { if (recorder_) d_->pending_.push_back({index_, recorder_->codes()}); }
         bool hooked() const { return bool(recorder_); }
         int get(uint8_t *state) { return recorder_->get(state); }
         int get_bypass() { return recorder_->get_bypass(); }
@@ -374,13 +371,15 @@ class decompressor {                                     // recode.cpp:1319-1598
         return index;
     }
 
-    void code_pending() {                                // one K1 batch for the whole file
+    // One K1 batch for the whole file, from resolved codes: the recorder has *state in hand at every bin
+    // (it is what updates it), so the (symbol, *state) pair of cabac::encoder::put (cabac_code.h:33) is
+    // shipped as one byte and the GPU skips working the states out again.
+    void code_pending() {
         if (pending_.empty()) return;
         size_t bins = 0;
-        for (auto &p : pending_) bins += p.recs.size();
-        batch_holder bh(device_, pending_.size(), bins + 8);
-        for (auto &p : pending_)
-            gpu_check(avr_batch_add_slice_cabac(bh.b, p.recs.data(), p.recs.size(), p.init_states.data(), AVR_MAX_STATES));
+        for (auto &p : pending_) bins += p.codes.size();
+        batch_holder bh(device_, pending_.size(), bins + 16 * pending_.size() + 64);
+        for (auto &p : pending_) gpu_check(avr_batch_add_slice_codes(bh.b, p.codes.data(), p.codes.size()));
         gpu_check(avr_batch_run(bh.b));
         for (size_t i = 0; i < pending_.size(); i++) {
             const uint8_t *bytes; size_t len; int status;
@@ -393,7 +392,7 @@ class decompressor {                                     // recode.cpp:1319-1598
         pending_.clear();
     }
 
-    struct pending { int index; std::vector<uint16_t> recs; std::vector<uint8_t> init_states; };
+    struct pending { int index; std::vector<uint8_t> codes; };
     int device_;
     Recoded in_;
     int read_index_ = 0, read_offset_ = 0;

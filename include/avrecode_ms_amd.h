@@ -78,6 +78,7 @@ extern "C" {
 
 #define AVR_KIND_CABAC 0         /* K1: cabac::encoder           (cabac_code.h:26-82)   */
 #define AVR_KIND_RANGE 1         /* K2: recoded_code::encoder    (recode.cpp:322-323)   */
+#define AVR_KIND_CABAC_CODES 2   /* K1 from resolved codes: one byte per bin, see avr_batch_add_slice_codes */
 
 const char *avr_last_error(void);
 const char *avr_version(void);
@@ -109,6 +110,12 @@ int        avr_batch_reset(avr_batch *b);
 int avr_batch_add_slice_cabac(avr_batch *b, const uint16_t *recs, size_t n,
                               const uint8_t *init_states, size_t n_states);
 int avr_batch_add_slice_range(avr_batch *b, const uint16_t *recs, size_t n);
+/* K1 from RESOLVED CODES: one byte per bin made with AVR_CODE_CONTEXT(state, bin) -- `state` being *state
+ * as it is when the bin is requested, which the adapter holds anyway (it updates it, cabac_code.h:43-47) --
+ * AVR_CODE_BYPASS(bin) or AVR_CODE_TERMINATE(bin): the (symbol, *state) pairs cabac::encoder::put takes
+ * (cabac_code.h:33).  Half the bytes of avr_batch_add_slice_cabac over PCIe, no state arrays, and the
+ * context-state resolution on the GPU is skipped.  put_terminate(1), if present, must be the last bin. */
+int avr_batch_add_slice_codes(avr_batch *b, const uint8_t *codes, size_t n);
 
 int avr_batch_run(avr_batch *b);
 

@@ -83,6 +83,40 @@ def test_chunked_every_context_count_and_length_class(avr, oracle, n_ctx):
         assert fs[i][:n_ctx].tobytes() == want[1], f"final states of slice {i}"
 
 
+def test_batch_api_from_resolved_codes(avr, oracle):
+    """avr_batch_add_slice_codes: the adapter resolves (symbol, *state) itself (cabac_code.h:33, 43-47) and
+    ships one byte per bin; no state arrays, half the bytes over PCIe, phase A skipped."""
+    lps, mlps = avr.cabac_tables()
+    rng = np.random.default_rng(404)
+    slices, codes = [], []
+    for i in range(24):
+        n = int(rng.integers(0, 40000)) if i else 0
+        recs, st = oracle_lib.random_cabac_stream(rng, n, int(rng.integers(1, 300)), terminate=bool(i % 5))
+        if i % 6 == 0:
+            st[:] = rng.integers(0, 128, st.size)
+        state = [int(x) for x in st]
+        out = np.zeros(recs.size, np.uint8)
+        for j, r in enumerate(recs):                        # what a hook adapter does per bin
+            b, sel = int(r) & 1, int(r) >> 1
+            if sel < 1024:
+                s = state[sel]
+                out[j] = 255 - ((b ^ s) & 1) if s >= 126 else (s << 1) | b                       # AVR_CODE_CONTEXT
+                state[sel] = mlps[127 - s] if b != (s & 1) else mlps[128 + s]                  # cabac_code.h:43-47
+            else:
+                out[j] = (252 | b) if sel == 1024 else 255 - b                                   # AVR_CODE_BYPASS / _TERMINATE
+        slices.append((recs, st)); codes.append(out)
+    b = avr.Batch(0, len(codes), sum(c.size for c in codes) + 64)
+    for c in codes:
+        b.add_codes(c)
+    b.run()
+    for i, (r, s) in enumerate(slices):
+        data, status = b.get(i)
+        assert status == 0 and data == oracle.cabac_encode(r, s)[0], f"slice {i}"
+    with pytest.raises(avr.AvrError):
+        b.get_states(0)                                      # there are no state arrays in this kind
+    b.close()
+
+
 def test_chunked_very_long_slices(avr, oracle):
     """More than 1024 chunks per slice: the per-slice kernels (B2, D) go through several tiles."""
     rng = np.random.default_rng(2024)
