@@ -12,7 +12,7 @@
 //   K2: pos = neg = 0 (never valid in a real record) -> skipped
 #define AVR_NOP_CABAC2  (AVR_NOP_CABAC | (AVR_NOP_CABAC << 16))
 // transient per-slice status: K1p declined the slice, k_cabac_encode codes it in the same call
-#define AVR_SLICE_RETRY_SERIAL 100
+#define AVR_SLICE_RETRY_SERIAL AVR_SLICE_NOT_CODED   /* internal name: "hand the slice to the serial kernel" */
 
 namespace avr {
 

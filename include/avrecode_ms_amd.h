@@ -62,6 +62,11 @@ extern "C" {
 #define AVR_SLICE_ZERO_PROB   1  /* arithmetic_code.h:116-118 "emitted a zero-probability symbol" */
 #define AVR_SLICE_OVERFLOW    2  /* output region too small (never with the batch API's sizing) */
 #define AVR_SLICE_BAD_RECORD  3  /* selector out of range, or a bin after put_terminate(1) */
+#define AVR_SLICE_NOT_CODED   100 /* only from the resolved-code entry points (avr_cabac_encode_resolved_device,
+                                   * avr_batch_add_slice_codes): the parallel scheme met a carry pattern it does not
+                                   * resolve (two overlapping windows and 33 particular digits; not observed) and
+                                   * there are no records to recode the slice from.  With records the serial kernel
+                                   * recodes such a slice in the same call and the status stays 0. */
 
 #define AVR_SEL_BYPASS     1024
 #define AVR_SEL_TERMINATE  1025
