@@ -110,6 +110,8 @@ SIGNATURES = {
     "avr_cabac_resolved_workspace_bytes": (c_size_t, [c_size_t, c_void_p]),
     "avr_cabac_encode_resolved_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,
                                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "avr_cabac_encode_codes_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "avr_cabac_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "avr_range_encode_slices_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

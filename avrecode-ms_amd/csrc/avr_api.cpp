@@ -168,7 +168,7 @@ avr_batch *avr_batch_create(int device, size_t max_slices, size_t max_bins) {
     b->max_bins = max_bins;
     bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 5; i++) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
-    ok = ok && b->h_recs.reserve(max_bins + 8 * max_slices) == AVR_OK;
+    ok = ok && b->h_recs.reserve(max_bins + 16 * max_slices) == AVR_OK;   // records: n + 7 per slice; codes (bytes): n + 31
     if (!ok) {
         if (!g_err[0]) fail(AVR_ERR_HIP, "stream/event creation failed");
         avr_batch_destroy(b);
@@ -257,7 +257,7 @@ int avr_batch_add_slice_codes(avr_batch *b, const uint8_t *codes, size_t n) {
     if (b->n_bins.size() >= b->max_slices) return fail(AVR_ERR_CAPACITY, "batch holds max_slices=%zu slices", b->max_slices);
     if (b->total_bins + n > b->max_bins) return fail(AVR_ERR_CAPACITY, "batch holds max_bins=%zu records", b->max_bins);
     const uint64_t off = b->rec_off.back(), padded = ((uint64_t(n) + 15) & ~uint64_t(15)) + 16;
-    if (off + padded > (b->max_bins + 8 * b->max_slices) * sizeof(uint16_t))
+    if (off + padded > (b->max_bins + 16 * b->max_slices) * sizeof(uint16_t))
         return fail(AVR_ERR_CAPACITY, "batch code buffer full (%zu slices)", b->n_bins.size());
     uint8_t *dst = reinterpret_cast<uint8_t *>(b->h_recs.p) + off;
     if (n) memcpy(dst, codes, n);
@@ -306,13 +306,29 @@ static int run_codes(avr_batch *b, uint32_t n32) {
     AVR_HIP(hipMemcpyAsync(b->d_out_off.p, out_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
     AVR_HIP(hipMemcpyAsync(b->d_n_bins.p, b->n_bins.data(), n * 4, hipMemcpyHostToDevice, s));
     AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
+    // few, long slices: the intra-slice parallel kernels; many short ones: one lane per slice (same rule as for records)
+    bool chunked = n <= 32768 && b->total_bins / n >= 8192;
+    if (const char *force = getenv("AVR_K1_PATH")) chunked = strcmp(force, "chunked") == 0;
+    std::vector<uint32_t> order;
+    if (!chunked) {
+        std::vector<uint64_t> tile_off;
+        plan_tiles(b->n_bins, order, tile_off);                  // longest first: the lanes of a wave finish together
+        if ((rc = b->d_order.reserve(n))) return rc;
+        AVR_HIP(hipMemcpyAsync(b->d_order.p, order.data(), n * 4, hipMemcpyHostToDevice, s));
+    }
     AVR_HIP(hipStreamSynchronize(s));                            // the plan vectors are pageable locals
     AVR_HIP(hipEventRecord(b->ev[1], s));
     AVR_HIP(hipEventRecord(b->ev[2], s));
-    uint8_t *wsp = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(b->d_workspace.p) + 255) & ~uintptr_t(255));
-    AVR_HIP(avr::launch_k1p_code(s, reinterpret_cast<const uint8_t *>(b->d_recs.p), b->d_n_bins.p, n32, &plan, wsp, b->d_out.p,
-                                 b->d_out_off.p, b->d_out_len.p, b->d_status.p));
-    b->last_path = 1;
+    const uint8_t *d_codes = reinterpret_cast<const uint8_t *>(b->d_recs.p);
+    if (chunked) {
+        uint8_t *wsp = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(b->d_workspace.p) + 255) & ~uintptr_t(255));
+        AVR_HIP(avr::launch_k1p_code(s, d_codes, b->d_n_bins.p, n32, &plan, wsp, b->d_out.p, b->d_out_off.p, b->d_out_len.p,
+                                     b->d_status.p));
+    } else {
+        AVR_HIP(avr::launch_cabac_encode_codes(s, d_codes, b->d_res_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_out.p,
+                                               b->d_out_off.p, b->d_out_len.p, b->d_status.p));
+    }
+    b->last_path = chunked;
     return fetch_output(b, out_off, n32);
 }
 
@@ -321,9 +337,8 @@ int avr_batch_run(avr_batch *b) {
     if (b->ran) return fail(AVR_ERR_INVALID, "batch already ran");
     if (int rc = select_device(b->device)) return rc;
     const size_t n = b->n_bins.size();
-    b->ran = true;
     b->dense_off.assign(n + 1, 0);
-    if (n == 0) return AVR_OK;
+    if (n == 0) { b->ran = true; return AVR_OK; }
     const uint32_t n32 = uint32_t(n);
     if (b->kind == AVR_KIND_CABAC_CODES) return run_codes(b, n32);
     const size_t ns = b->n_states;
@@ -361,12 +376,18 @@ int avr_batch_run(avr_batch *b) {
     // the vectors above are pageable: the copies have been staged by the runtime when the calls return
     AVR_HIP(hipEventRecord(b->ev[1], s));
     AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
+    // One lane per slice needs tens of thousands of slices to fill the chip; a batch of few, long
+    // slices (a clip with one slice per frame) goes through the intra-slice parallel kernels.
+    bool chunked = cabac && n <= 32768 && b->total_bins / n >= 8192;
+    if (const char *force = getenv("AVR_K1_PATH")) chunked = cabac && strcmp(force, "chunked") == 0;
+    b->last_path = chunked;
     // Renumber the batch onto the contexts it uses (K1 keeps 64 x n_states state bytes in LDS per wave).
+    // The intra-slice parallel kernels do this themselves, inside their histogram pass.
     const uint8_t *k_states = b->d_states.p;
     uint8_t *k_final = b->d_final.p;
     size_t k_ns = ns;
     b->n_dense = 0;
-    if (cabac && ns > 1 && !getenv("AVR_NO_DENSE")) {
+    if (cabac && !chunked && ns > 1 && !getenv("AVR_NO_DENSE")) {
         if ((rc = b->d_bitmap.reserve(32)) || (rc = b->d_table.reserve(1024)) || (rc = b->d_index.reserve(1024))) return rc;
         AVR_HIP(hipMemsetAsync(b->d_bitmap.p, 0, 32 * sizeof(uint32_t), s));
         AVR_HIP(avr::launch_context_census(s, b->d_recs.p, total_recs, b->d_bitmap.p));
@@ -390,11 +411,6 @@ int avr_batch_run(avr_batch *b) {
             b->n_dense = index.size() ? index.size() : size_t(-1);
         }
     }
-    // One lane per slice needs tens of thousands of slices to fill the chip; a batch of few, long
-    // slices (a clip with one slice per frame) goes through the intra-slice parallel kernels.
-    bool chunked = cabac && n <= 32768 && b->total_bins / n >= 8192;
-    if (const char *force = getenv("AVR_K1_PATH")) chunked = cabac && strcmp(force, "chunked") == 0;
-    b->last_path = chunked;
     if (chunked) {
         std::vector<uint64_t> res_off(n + 1, 0), dig_off(n + 1, 0);
         std::vector<uint32_t> chunk_base(n + 1, 0), blk_base(n + 1, 0), chunk_slice, blk_slice;
@@ -471,6 +487,7 @@ static int fetch_output(avr_batch *b, const std::vector<uint64_t> &out_off, uint
     AVR_HIP(hipEventRecord(b->ev[4], s));
     AVR_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&b->ms[i], b->ev[i], b->ev[i + 1]);
+    b->ran = true;                                               // only now: the getters hand out h_out / h_status
     return AVR_OK;
 }
 
@@ -604,6 +621,17 @@ int avr_cabac_encode_resolved_device(int device, void *stream, const uint8_t *co
     if (int rc = select_device(device)) return rc;
     AVR_HIP(avr::launch_k1p_code(static_cast<hipStream_t>(stream), codes, n_bins, uint32_t(n_slices), plan, workspace, out, out_off,
                                  out_len, status));
+    return AVR_OK;
+}
+
+int avr_cabac_encode_codes_device(int device, void *stream, const uint8_t *codes, const uint64_t *res_off, const uint32_t *n_bins,
+                                  const uint32_t *order, size_t n_slices, uint8_t *out, const uint64_t *out_off,
+                                  uint32_t *out_len, int32_t *status) {
+    if (int rc = check_common(codes, n_bins, out_off, n_slices)) return rc;
+    if (n_slices && (!res_off || !status || !out_len)) return fail(AVR_ERR_INVALID, "null device pointer");
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_cabac_encode_codes(static_cast<hipStream_t>(stream), codes, res_off, n_bins, order, uint32_t(n_slices), out,
+                                           out_off, out_len, status));
     return AVR_OK;
 }
 

@@ -12,7 +12,8 @@
 //   K2: pos = neg = 0 (never valid in a real record) -> skipped
 #define AVR_NOP_CABAC2  (AVR_NOP_CABAC | (AVR_NOP_CABAC << 16))
 // transient per-slice status: K1p declined the slice, k_cabac_encode codes it in the same call
-#define AVR_SLICE_RETRY_SERIAL AVR_SLICE_NOT_CODED   /* internal name: "hand the slice to the serial kernel" */
+// (never leaves a call: k_cabac_encode / k_cabac_encode_codes replace it with the slice's real status)
+#define AVR_SLICE_RETRY_SERIAL 100
 
 namespace avr {
 
@@ -55,6 +56,9 @@ size_t k1p_code_workspace_bytes(size_t n_slices, const avr_chunk_plan *pl);
 hipError_t launch_k1p_code(hipStream_t s, const uint8_t *codes, const uint32_t *n_bins, uint32_t n_slices,
                            const avr_chunk_plan *pl, void *workspace, uint8_t *out, const uint64_t *out_off,
                            uint32_t *out_len, int32_t *status);
+hipError_t launch_cabac_encode_codes(hipStream_t s, const uint8_t *codes, const uint64_t *res_off, const uint32_t *n_bins,
+                                     const uint32_t *order, uint32_t n_slices, uint8_t *out, const uint64_t *out_off,
+                                     uint32_t *out_len, int32_t *status, int32_t want_status = AVR_SLICE_OK);
 hipError_t launch_synth_slices(hipStream_t s, int workload, uint32_t scale, uint64_t seed, uint64_t first_slice,
                                int kind, uint32_t n_slices, const uint64_t *rec_off, uint16_t *recs,
                                uint8_t *init_states, uint32_t n_states);

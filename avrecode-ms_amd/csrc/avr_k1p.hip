@@ -22,7 +22,9 @@
 // a slice the scheme declines (no coded LPS for 16 chunks) is coded by k_cabac_encode itself.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
+#include "avr_coder.h"
 #include "avr_internal.h"
 #include "avr_k1p.h"
 #include "avr_tables.h"
@@ -43,17 +45,29 @@ struct Plan {                       // device pointers of the caller's plan (avr
     const uint32_t *chunk_base, *chunk_slice;
     const uint32_t *blk_base, *blk_slice;
     const uint64_t *dig_off;
-    uint32_t n_states;              // contexts per slice (sort keys)
+    uint32_t n_states;              // sort keys: the contexts the batch uses, numbered densely 0 .. n_states-1 (k_k1p_densemap)
+    uint32_t ns_full;               // contexts per slice as the caller numbers them (init_states / final_states rows)
+    const uint16_t *table;          // [1024] caller's context number -> dense id (kNotUsed: occurs nowhere in the batch)
+    const uint16_t *index;          // [n_states] dense id -> caller's context number
 };
+constexpr uint32_t kNotUsed = 0xffffu;
 
 // ------------------------------------------------------------------ phase A
 
 // Also the one place every record of this path is examined: a selector that is no context of the
 // slice, bypass or terminate, or a bin after put_terminate(1), flags the slice AVR_SLICE_BAD_RECORD.
-__global__ __launch_bounds__(256) void k_k1p_hist(Plan p, int32_t *status, uint32_t *hist) {
+//
+// Contexts are counted under the caller's numbering (the offset of the state byte in cabac_state[],
+// recode.cpp:325: up to 1024, of which a stream touches few).  The census of the contexts the batch
+// uses falls out of the same pass -- the non-zero columns -- as a 1024-bit map; k_k1p_densemap turns it
+// into the dense numbering every later kernel sorts and indexes by, applied to the records as they are
+// loaded (one LDS look-up), so no pass over the records exists for the renumbering.
+__global__ __launch_bounds__(256) void k_k1p_hist(Plan p, int32_t *status, uint16_t *hist16, uint32_t *used) {
     __shared__ uint32_t cnt[AVR_MAX_STATES];
-    const uint32_t b = blockIdx.x, s = p.blk_slice[b], nk = p.n_states;
+    __shared__ uint32_t bm[32];
+    const uint32_t b = blockIdx.x, s = p.blk_slice[b], nk = p.ns_full;
     for (uint32_t k = threadIdx.x; k < nk; k += 256) cnt[k] = 0;
+    if (threadIdx.x < 32) bm[threadIdx.x] = 0;
     __syncthreads();
     if (status[s] == AVR_SLICE_OK) {
         const uint32_t n = p.n_bins[s], i0 = (b - p.blk_base[s]) * kSortBlock;
@@ -83,26 +97,58 @@ __global__ __launch_bounds__(256) void k_k1p_hist(Plan p, int32_t *status, uint3
         if (bad) status[s] = AVR_SLICE_BAD_RECORD;
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < nk; k += 256) hist[size_t(b) * nk + k] = cnt[k];
+    for (uint32_t k = threadIdx.x; k < nk; k += 256) {
+        const uint32_t c = cnt[k];
+        hist16[size_t(b) * nk + k] = uint16_t(c);                // <= kSortBlock
+        if (c) atomicOr(&bm[k >> 5], 1u << (k & 31));
+    }
+    __syncthreads();
+    // bits only ever get set, so a (possibly stale) plain read tells which are still missing: after the
+    // first few blocks nothing is, and no block touches the shared words any more
+    if (threadIdx.x < 32) {
+        const uint32_t mine = bm[threadIdx.x];
+        if (mine & ~__hip_atomic_load(&used[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&used[threadIdx.x], mine);
+    }
 }
 
-// hist[b][k] -> position (within the slice's sorted order) of the first bin of context k in block b;
-// run_start[s][k] = first position of context k, run_start[s][nk] = number of context bins.
-__global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, uint32_t *hist, uint32_t *run_start) {
+// used (1024 bits) -> table[caller's number] = dense id, index[dense id] = caller's number, *n_dense.
+__global__ __launch_bounds__(1024) void k_k1p_densemap(const uint32_t *used, uint16_t *table, uint16_t *index, uint32_t *n_dense) {
     __shared__ uint32_t sc[1024];
-    const uint32_t s = blockIdx.x, k = threadIdx.x, nk = p.n_states;
+    const uint32_t k = threadIdx.x;
+    const uint32_t bit = (used[k >> 5] >> (k & 31)) & 1u;
+    sc[k] = bit;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = k >= d ? sc[k - d] : 0;
+        __syncthreads();
+        sc[k] += v;
+        __syncthreads();
+    }
+    const uint32_t id = sc[k] - bit;
+    table[k] = bit ? uint16_t(id) : uint16_t(kNotUsed);
+    if (bit) index[id] = uint16_t(k);
+    if (k == 1023) *n_dense = sc[1023];
+}
+
+// hist16[b][caller's number] -> boff[b][k] = position (within the slice's sorted order) of the first bin of
+// context k (dense) in block b; run_start[s][k] = first position of context k, run_start[s][nk] = number of
+// context bins.
+__global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, const uint16_t *hist16, uint32_t *boff, uint32_t *run_start) {
+    __shared__ uint32_t sc[1024];
+    const uint32_t s = blockIdx.x, k = threadIdx.x, nk = p.n_states, ns = p.ns_full;
     const uint32_t b0 = p.blk_base[s], b1 = p.blk_base[s + 1];
+    const uint32_t col = k < nk ? p.index[k] : 0;
     uint32_t total = 0;
     if (k < nk) {
         uint32_t b = b0;
         for (; b + 8 <= b1; b += 8) {                            // eight loads in flight: the loop is their latency
             uint32_t c[8];
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) c[j] = hist[size_t(b + j) * nk + k];
+            for (uint32_t j = 0; j < 8; j++) c[j] = hist16[size_t(b + j) * ns + col];
 #pragma unroll
             for (uint32_t j = 0; j < 8; j++) total += c[j];
         }
-        for (; b < b1; b++) total += hist[size_t(b) * nk + k];
+        for (; b < b1; b++) total += hist16[size_t(b) * ns + col];
     }
     sc[k] = total;
     __syncthreads();
@@ -119,13 +165,13 @@ __global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, uint32_t *hist, uint3
         for (; b + 8 <= b1; b += 8) {
             uint32_t c[8];
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) c[j] = hist[size_t(b + j) * nk + k];
+            for (uint32_t j = 0; j < 8; j++) c[j] = hist16[size_t(b + j) * ns + col];
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) { hist[size_t(b + j) * nk + k] = run; run += c[j]; }
+            for (uint32_t j = 0; j < 8; j++) { boff[size_t(b + j) * nk + k] = run; run += c[j]; }
         }
         for (; b < b1; b++) {
-            const uint32_t c = hist[size_t(b) * nk + k];
-            hist[size_t(b) * nk + k] = run;
+            const uint32_t c = hist16[size_t(b) * ns + col];
+            boff[size_t(b) * nk + k] = run;
             run += c;
         }
     }
@@ -155,6 +201,7 @@ __global__ __launch_bounds__(256, 8) void k_k1p_scatter(Plan p, const int32_t *s
     uint32_t *delta = cnt + 4 * nk_pad;                          // global position - local position
     uint16_t *kbuf = reinterpret_cast<uint16_t *>(delta + nk_pad);   // context of every locally sorted bin
     uint8_t *lbuf = reinterpret_cast<uint8_t *>(kbuf + kSortBlock);  // the bins, locally sorted
+    __shared__ uint16_t tab[1024];                               // caller's context number -> dense id
     __shared__ uint32_t sh_n_local;
     const uint32_t b = blockIdx.x, s = p.blk_slice[b], t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (status[s] != AVR_SLICE_OK) return;
@@ -173,10 +220,13 @@ __global__ __launch_bounds__(256, 8) void k_k1p_scatter(Plan p, const int32_t *s
         for (uint32_t j = 0; j < kQuarterBatches; j++) recs[j] = q0 + 64 * j + lane < i1 ? rq[64 * j] : uint32_t(AVR_NOP_CABAC);
     }
     for (uint32_t k = t; k < 4 * nk_pad; k += 256) cnt[k] = 0;
+    for (uint32_t k = t; k < 1024; k += 256) tab[k] = p.table[k];
     __syncthreads();
 #pragma unroll
-    for (uint32_t j = 0; j < kQuarterBatches; j++) {             // count the quarter
-        const uint32_t sel = (recs[j] >> 1) & 0x7ffu;
+    for (uint32_t j = 0; j < kQuarterBatches; j++) {             // renumber (dense ids), count the quarter
+        const uint32_t raw = (recs[j] >> 1) & 0x7ffu;
+        const uint32_t sel = raw < 1024u ? uint32_t(tab[raw]) : raw | 0x8000u;      // not a context: anything >= nk
+        recs[j] = (recs[j] & 1u) | (sel << 1);
         if (sel < nk) atomicAdd(&cnt[w * nk_pad + sel], 1u);
     }
     __syncthreads();
@@ -225,7 +275,7 @@ __global__ __launch_bounds__(256, 8) void k_k1p_scatter(Plan p, const int32_t *s
         uint32_t rec = recs[j];
         asm volatile("" : "+v"(rec));                            // keeps this batch's ballots here: hoisted to the top, the 16 x KEY_BITS
                                                                  // lane masks outlive the SGPR file and are spilled (measured 1.45x slower)
-        const uint32_t sel = (rec >> 1) & 0x7ffu;
+        const uint32_t sel = rec >> 1;
         const bool is_ctx = sel < nk;
         // lanes holding the same context: for every key bit keep the lanes whose bit equals mine,
         // mask &= ~(ballot(bit) ^ (my bit ? ~0 : 0)), one three-input bit operation per half
@@ -343,7 +393,7 @@ __global__ __launch_bounds__(256) void k_k1p_spec(Plan p, uint32_t total_chunks,
     if (status[s] != AVR_SLICE_OK || from >= rs[nk]) { seg[gc] = o; return; }
     const uint32_t to = from + kChunk < rs[nk] ? from + kChunk : rs[nk];
     uint8_t *so = sorted + p.res_off[s];
-    const uint8_t *init = init_states + size_t(s) * nk;
+    const uint8_t *init = init_states + size_t(s) * p.ns_full;   // rows in the caller's numbering
     const uint32_t k0 = run_of(rs, nk, from);
     o.empty = 0;
     o.k_first = k0;
@@ -351,7 +401,7 @@ __global__ __launch_bounds__(256) void k_k1p_spec(Plan p, uint32_t total_chunks,
     const uint32_t k1 = run_of(rs, nk, to - 1);                 // the run the segment is left in
     o.leaves_mid = rs[k1 + 1] > to;
     if (o.leaves_mid) {
-        const uint32_t i0 = init[k1] & 127u;
+        const uint32_t i0 = init[p.index[k1]] & 127u;
         uint32_t a, b;
         if (k1 == k0 && o.enters_mid && i0 < 126) { a = 124; b = 125; }        // entered and left in the same run
         else a = b = i0;                                          // the run starts here, or its state never moves
@@ -416,26 +466,25 @@ __global__ __launch_bounds__(256) void k_k1p_chain(Plan p, uint32_t total_chunks
     const uint32_t s = p.chunk_slice[gc], nk = p.n_states;
     if (status[s] != AVR_SLICE_OK) return;
     const uint32_t *rs = run_start + size_t(s) * (nk + 1);
-    const uint8_t *init = init_states + size_t(s) * nk;
-    uint8_t *fin = final_states ? final_states + size_t(s) * nk : nullptr;
+    // rows of init_states / final_states are in the caller's numbering; final_states starts out as a copy of
+    // init_states (launch_resolve), so only contexts that have bins in the slice are written here
+    const uint8_t *init = init_states + size_t(s) * p.ns_full;
+    uint8_t *fin = final_states ? final_states + size_t(s) * p.ns_full : nullptr;
+    const uint16_t *idx = p.index;
     const uint32_t c = gc - p.chunk_base[s], from = c * kChunk;
     const Seg me = seg[gc];
-    if (me.empty) {                                              // only segment 0 of a slice without context bins matters
-        if (c == 0 && fin) for (uint32_t k = 0; k < nk; k++) fin[k] = init[k];
-        return;
-    }
+    if (me.empty) return;
     const uint32_t to = from + kChunk < rs[nk] ? from + kChunk : rs[nk];
     uint8_t *so = sorted + p.res_off[s];
     uint32_t k = me.k_first;
-    uint32_t st = me.enters_mid ? uint32_t(entry[gc]) : (init[k] & 127u);
+    uint32_t st = me.enters_mid ? uint32_t(entry[gc]) : (init[idx[k]] & 127u);
     uint32_t run_end = rs[k + 1];                                // > from: the segment's first position lies in run k
-    if (c == 0 && fin) for (uint32_t e = 0; e < k; e++) fin[e] = init[e];       // empty runs before the first bin
     // run k ends at `run_end`: its final state, then on to the next run that has bins
     auto next_run = [&]() {
-        if (fin) fin[k] = uint8_t(st);
+        if (fin) fin[idx[k]] = uint8_t(st);
         k++;
-        while (k < nk && rs[k + 1] == rs[k]) { if (fin) fin[k] = init[k]; k++; }
-        if (k < nk) { st = init[k] & 127u; run_end = rs[k + 1]; } else run_end = 0xffffffffu;
+        while (k < nk && rs[k + 1] == rs[k]) k++;
+        if (k < nk) { st = init[idx[k]] & 127u; run_end = rs[k + 1]; } else run_end = 0xffffffffu;
     };
     // The segment is walked in aligned 16-byte groups whatever runs it holds (a cold context's run is
     // a few bins: walking run by run would mean byte loads and stores for most of such a segment).
@@ -520,24 +569,26 @@ __global__ __launch_bounds__(256) void k_k1p_entry(Plan p, uint32_t total_chunks
     if (c * kChunk >= p.n_bins[s]) return;
     const uint8_t *so = sorted + p.res_off[s];
     const uint32_t *bo = qoff + (size_t(p.blk_base[s]) * 4 + c) * nk;    // chunk c is quarter c & 3 of sort block c >> 2
-    const uint8_t *init = init_states + size_t(s) * nk;
+    const uint8_t *init = init_states + size_t(s) * p.ns_full;
     uint32_t word = 0;
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
         const uint32_t k = k0 + j < nk ? k0 + j : nk - 1;
         const uint32_t cd = so[bo[k]];
-        word |= (cd < 252 ? cd >> 1 : init[k] & 127u) << (8 * j);           // pStateIdx 63 never moves
+        word |= (cd < 252 ? cd >> 1 : init[p.index[k]] & 127u) << (8 * j);  // pStateIdx 63 never moves
     }
     est[size_t(gc) * nkw + kw] = word;
 }
 
-__global__ __launch_bounds__(64) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *est, uint8_t *res,
-                                                   const int32_t *status) {
-    extern __shared__ uint32_t replay_lds[];                     // T[kReplayTable], then state dwords [(nk+8)/4][64]
+__global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *est, uint8_t *res,
+                                                    const int32_t *status) {
+    extern __shared__ uint32_t replay_lds[];                     // T[kReplayTable], then per wave: state dwords [(nk+8)/4][64]
+    __shared__ uint16_t tab[1024];                               // caller's context number -> dense id
     uint32_t *T = replay_lds;
-    const uint32_t lane = threadIdx.x, nk = p.n_states;
-    uint8_t *stb = reinterpret_cast<uint8_t *>(replay_lds + kReplayTable) + lane * 4;
-    for (uint32_t st = lane; st < kReplayTable; st += 64) {
+    const uint32_t lane = threadIdx.x & 63, nk = p.n_states;
+    uint8_t *stb = reinterpret_cast<uint8_t *>(replay_lds + kReplayTable) + (threadIdx.x >> 6) * (((nk + 8) >> 2) << 8) + lane * 4;
+    for (uint32_t k = threadIdx.x; k < 1024; k += 256) tab[k] = p.table[k];
+    for (uint32_t st = threadIdx.x; st < kReplayTable; st += 256) {
         uint32_t e;
         if (st < 128) e = d_tables.packed[st][1] | code_context(st, 0) << 16 | code_context(st, 1) << 24;
         else {
@@ -548,7 +599,7 @@ __global__ __launch_bounds__(64) void k_k1p_replay(Plan p, uint32_t total_chunks
         T[st] = e;
     }
     __syncthreads();
-    const uint32_t gc = blockIdx.x * 64 + lane;
+    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
     if (gc >= total_chunks) return;
     const uint32_t s = p.chunk_slice[gc];
     if (status[s] != AVR_SLICE_OK) return;
@@ -574,9 +625,10 @@ __global__ __launch_bounds__(64) void k_k1p_replay(Plan p, uint32_t total_chunks
         for (uint32_t j = 0; j < 8; j++) {
             const uint32_t rec = w[j >> 1] >> ((j & 1) * 16);
             const uint32_t sel = (rec >> 1) & 0x7ffu, bin = rec & 1;
-            // contexts keep their number; 1024 (bypass), 1025 (terminate), 1026 (no-op) -> nk+1, nk+2, nk+3
+            // contexts get their dense id; 1024 (bypass), 1025 (terminate), 1026 (no-op) -> nk+1, nk+2, nk+3
             const uint32_t over = (sel < 1023u ? 1023u : sel > 1027u ? 1027u : sel) - 1023u;
-            const uint32_t kk = (sel < nk ? sel : nk) + over;
+            const uint32_t dense = tab[sel & 1023u];
+            const uint32_t kk = (sel < 1024u && dense < nk ? dense : nk) + over;
             uint8_t *sp = stb + ((kk & ~3u) << 6) + (kk & 3);
             const uint32_t st = *sp;
             const uint32_t e = T[st];
@@ -751,7 +803,7 @@ constexpr uint32_t kTile = 256 * kSeg;
 
 __global__ __launch_bounds__(256) void k_k1p_d(Plan p, const SliceTotals *tot, const uint32_t *S,
                                                uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
-                                               int32_t *status) {
+                                               int32_t *status, uint32_t force_retry_every) {
     __shared__ uint32_t dig[kTile];
     __shared__ uint32_t seg_g[256], seg_cin[256];
     __shared__ uint64_t seg_gm[4], seg_pm[4];
@@ -759,7 +811,10 @@ __global__ __launch_bounds__(256) void k_k1p_d(Plan p, const SliceTotals *tot, c
     const uint32_t s = blockIdx.x, t = threadIdx.x;
     if (status[s] != AVR_SLICE_OK) { if (t == 0) out_len[s] = 0; return; }
     const SliceTotals T = tot[s];
-    if (T.bad) { if (t == 0) status[s] = AVR_SLICE_RETRY_SERIAL; return; }
+    // force_retry_every (test switch AVR_K1P_FORCE_RETRY=n, 0 = off): every n-th slice is handed to the serial
+    // kernel as if phase D had met the carry pattern it does not resolve -- the hand-over is then proven on
+    // every run of the tests, not only when that pattern occurs
+    if (T.bad || (force_retry_every && s % force_retry_every == 0)) { if (t == 0) status[s] = AVR_SLICE_RETRY_SERIAL; return; }
     const uint32_t *Ss = S + p.dig_off[s];
     uint8_t *o = out + out_off[s];
     const uint32_t cap = uint32_t(out_off[s + 1] - out_off[s]);
@@ -839,6 +894,69 @@ __global__ __launch_bounds__(256) void k_k1p_d(Plan p, const SliceTotals *tot, c
     }
 }
 
+// ------------------------------------------------------------------ serial coder from resolved codes
+//
+// One lane per slice over one-byte resolved codes: each code IS the (symbol, *state) pair cabac::encoder::put
+// takes (cabac_code.h:33), so this is cabac_code.h:33-67 on arithmetic_code.h:106-126 with no state table at
+// all -- the per-code entry (LPS ranges of the state's four range quarters, coded symbol) comes from a
+// 256-entry LDS table.  Two uses: the slices phase D hands back (want_status = AVR_SLICE_RETRY_SERIAL: the
+// carry pattern of k_k1p_d, or the test switch), and batches of many short slices, where one lane per
+// slice fills the chip and the per-chunk machinery of K1p would be all overhead.
+// Slice i's codes are at codes + res_off[i] (16-byte aligned, readable up to the next multiple of 16).
+__global__ __launch_bounds__(64) void k_cabac_encode_codes(const uint8_t *codes_in, const uint64_t *res_off, const uint32_t *n_bins,
+                                                           const uint32_t *order, uint32_t n_slices, uint8_t *out,
+                                                           const uint64_t *out_off, uint32_t *out_len, int32_t *status,
+                                                           int32_t want_status) {
+    __shared__ CodeEntry codes[256];
+    for (uint32_t c = threadIdx.x; c < 256; c += 64) codes[c] = device_code_entry(c);
+    __syncthreads();
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_slices) return;
+    const uint32_t slice = order ? order[g] : g;
+    if (status[slice] != want_status) {
+        if (want_status == AVR_SLICE_OK) out_len[slice] = 0;
+        return;
+    }
+    const uint32_t n = n_bins[slice];
+    const uint8_t *res = codes_in + res_off[slice];
+    const uint64_t o0 = out_off[slice];
+    const uint32_t cap = uint32_t(out_off[slice + 1] - o0);
+    CabacEncoder e;
+    e.init(0x7F800000u, out + o0, cap);                          // cabac_code.h:30
+    auto bin = [&](uint32_t c) {
+        const CodeEntry ce = codes[c];
+        const int norm = 23 - __builtin_clz(e.range);            // cabac_code.h:37, 70-79
+        const uint32_t q = (e.range >> (norm + 6)) & 3;          // :39-40
+        const uint32_t r_tab = ((ce.row >> (8 * q)) & 0xffu) << norm;            // :40-41; put_terminate :59-60 is the row of pStateIdx 63
+        const uint32_t r1 = (ce.meta >> 8) ? e.range >> 1 : r_tab;               // put_bypass :52-54
+        const uint32_t sym = (ce.meta >> 1) & 1u;                // the coded symbol (for a bypass bin: the bin)
+        const uint32_t r0 = e.range - r1;                        // arithmetic_code.h:107-114
+        e.low += sym ? r0 : 0u;
+        e.range = sym ? r1 : r0;
+        if (e.range < 0x200u) e.emit_digit();                    // :115-122
+    };
+    uint32_t i = 0;
+    if (n >= 16) {
+        U4 v = *reinterpret_cast<const U4 *>(res);
+        for (; i + 16 <= n; i += 16) {                           // the next group is in flight while this one is coded
+            const U4 nx = i + 32 <= n ? *reinterpret_cast<const U4 *>(res + i + 16) : v;
+            uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
+#pragma unroll 1
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t d = w0;
+                w0 = w1; w1 = w2; w2 = w3;
+                bin(d & 0xffu); bin((d >> 8) & 0xffu); bin((d >> 16) & 0xffu); bin(d >> 24);
+            }
+            v = nx;
+        }
+    }
+    for (; i < n; i++) bin(res[i]);
+    e.finish();                                                  // cabac_code.h:63-65 / ~encoder(), arithmetic_code.h:100
+    e.w.flush();
+    out_len[slice] = e.w.n;
+    status[slice] = e.w.n > cap ? AVR_SLICE_OVERFLOW : AVR_SLICE_OK;
+}
+
 // ------------------------------------------------------------------ launcher
 
 namespace {
@@ -846,43 +964,83 @@ inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 }
 
 // Phase A: records + initial states -> resolved codes `res` (slice i at res + res_off[i]).
-// `w` is workspace for the sort (sorted bins, histograms, run starts, segments).
-static hipError_t launch_resolve(hipStream_t s, const Plan &p, uint32_t n_slices, const uint8_t *init_states,
+// `w` is workspace for the sort (sorted bins, histograms, run starts, segments), laid out for the
+// caller's context count; the kernels index it by the dense count, which is known after the histogram
+// pass (the one host round trip of the path: four bytes, to size the later launches).
+struct ResolveLayout {
+    uint64_t sorted, hist16, boff, run_start, seg, entry, qoff, est, meta, total;
+};
+static inline ResolveLayout resolve_layout(size_t n_slices, uint32_t ns, const avr_chunk_plan *pl) {
+    ResolveLayout L;
+    uint64_t at = 0;
+    auto take = [&](uint64_t bytes) { const uint64_t o = at; at += up256(bytes); return o; };
+    L.sorted = take(pl->res_total + 32);
+    L.hist16 = take(uint64_t(pl->total_blocks) * ns * 2 + 16);
+    L.boff = take(uint64_t(pl->total_blocks) * ns * 4 + 16);
+    L.run_start = take(n_slices * uint64_t(ns + 1) * 4 + 16);
+    L.seg = take(uint64_t(pl->total_chunks) * sizeof(Seg));
+    L.entry = take(uint64_t(pl->total_chunks) + 16);
+    L.qoff = take(uint64_t(pl->total_blocks) * ns * 16 + 16);
+    L.est = take(uint64_t(pl->total_chunks) * ((ns + 3) / 4) * 4 + 16);
+    L.meta = take(256 + 2048 + 2048);                            // used[32] + n_dense, table[1024], index[1024]
+    L.total = at;
+    return L;
+}
+
+static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const uint8_t *init_states,
                                  const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, int32_t *status, uint8_t *final_states) {
-    const uint32_t n_states = p.n_states;
-    uint8_t *sorted = w;                                     w += up256(pl->res_total + 32);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(w);        w += up256(uint64_t(pl->total_blocks) * n_states * 4 + 16);
-    uint32_t *run_start = reinterpret_cast<uint32_t *>(w);   w += up256(n_slices * uint64_t(n_states + 1) * 4 + 16);
-    Seg *seg = reinterpret_cast<Seg *>(w);                   w += up256(uint64_t(pl->total_chunks) * sizeof(Seg));
-    uint8_t *entry = w;                                      w += up256(uint64_t(pl->total_chunks) + 16);
-    uint32_t *qoff = reinterpret_cast<uint32_t *>(w);        w += up256(uint64_t(pl->total_blocks) * n_states * 16 + 16);
-    uint32_t *est = reinterpret_cast<uint32_t *>(w);
+    const uint32_t ns = p.ns_full;
+    const ResolveLayout L = resolve_layout(n_slices, ns, pl);
+    uint8_t *sorted = w + L.sorted;
+    uint16_t *hist16 = reinterpret_cast<uint16_t *>(w + L.hist16);
+    uint32_t *boff = reinterpret_cast<uint32_t *>(w + L.boff);
+    uint32_t *run_start = reinterpret_cast<uint32_t *>(w + L.run_start);
+    Seg *seg = reinterpret_cast<Seg *>(w + L.seg);
+    uint8_t *entry = w + L.entry;
+    uint32_t *qoff = reinterpret_cast<uint32_t *>(w + L.qoff);
+    uint32_t *est = reinterpret_cast<uint32_t *>(w + L.est);
+    uint32_t *used = reinterpret_cast<uint32_t *>(w + L.meta);   // [32], then n_dense
+    uint32_t *n_dense = used + 32;
+    uint16_t *table = reinterpret_cast<uint16_t *>(w + L.meta + 256), *index = table + 1024;
+    p.table = table;
+    p.index = index;
+    hipError_t e;
+    if ((e = hipMemsetAsync(used, 0, 256, s)) != hipSuccess) return e;
+    if (final_states && ns && (e = hipMemcpyAsync(final_states, init_states, size_t(n_slices) * ns, hipMemcpyDeviceToDevice, s)) != hipSuccess)
+        return e;                                                // contexts without bins keep their state
+    hipLaunchKernelGGL(k_k1p_hist, dim3(pl->total_blocks), dim3(256), 0, s, p, status, hist16, used);
+    hipLaunchKernelGGL(k_k1p_densemap, dim3(1), dim3(1024), 0, s, used, table, index, n_dense);
+    uint32_t n_states = 0;
+    if ((e = hipMemcpyAsync(&n_states, n_dense, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    p.n_states = n_states;
     uint32_t key_bits = 0;
     while ((1u << key_bits) < n_states) key_bits++;
     const uint32_t chunk_blocks = (pl->total_chunks + 255) / 256;
-    hipLaunchKernelGGL(k_k1p_hist, dim3(pl->total_blocks), dim3(256), 0, s, p, status, hist);
     if (n_states > 0) {
-        hipLaunchKernelGGL(k_k1p_scan, dim3(n_slices), dim3(1024), 0, s, p, hist, run_start);
+        hipLaunchKernelGGL(k_k1p_scan, dim3(n_slices), dim3(1024), 0, s, p, hist16, boff, run_start);
         const uint32_t scatter_lds = 20 * ((n_states + 63) & ~63u) + 3 * kSortBlock;
         auto scatter = key_bits <= 1 ? k_k1p_scatter<1> : key_bits == 2 ? k_k1p_scatter<2> : key_bits == 3 ? k_k1p_scatter<3> :
                        key_bits == 4 ? k_k1p_scatter<4> : key_bits == 5 ? k_k1p_scatter<5> : key_bits == 6 ? k_k1p_scatter<6> :
                        key_bits == 7 ? k_k1p_scatter<7> : key_bits == 8 ? k_k1p_scatter<8> : key_bits == 9 ? k_k1p_scatter<9> :
                                                                                                k_k1p_scatter<10>;
-        hipLaunchKernelGGL(scatter, dim3(pl->total_blocks), dim3(256), scatter_lds, s, p, status, hist, run_start, sorted, qoff);
+        hipLaunchKernelGGL(scatter, dim3(pl->total_blocks), dim3(256), scatter_lds, s, p, status, boff, run_start, sorted, qoff);
         hipLaunchKernelGGL(k_k1p_spec, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
                            sorted, seg);
         hipLaunchKernelGGL(k_k1p_link, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
                            sorted, seg, entry);
         hipLaunchKernelGGL(k_k1p_chain, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
                            sorted, seg, entry, final_states);
-    }
-    const uint32_t replay_lds = kReplayTable * 4 + ((n_states + 8) / 4) * 256;
-    if (n_states > 0) {
         const uint32_t nkw = (n_states + 3) / 4, cpb = 256 / nkw;           // nkw <= 256
         hipLaunchKernelGGL(k_k1p_entry, dim3((pl->total_chunks + cpb - 1) / cpb), dim3(256), 0, s, p, pl->total_chunks, status, qoff,
                            sorted, init_states, est, cpb, (65536 + nkw - 1) / nkw);
     }
-    hipLaunchKernelGGL(k_k1p_replay, dim3((pl->total_chunks + 63) / 64), dim3(64), replay_lds, s, p, pl->total_chunks, est, res, status);
+    const uint32_t replay_lds = kReplayTable * 4 + 4 * ((n_states + 8) / 4) * 256;
+    if (replay_lds > 64 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_k1p_replay), hipFuncAttributeMaxDynamicSharedMemorySize, int(replay_lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_k1p_replay, dim3(chunk_blocks), dim3(256), replay_lds, s, p, pl->total_chunks, est, res, status);
     return hipGetLastError();
 }
 
@@ -899,15 +1057,23 @@ static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, c
     hipLaunchKernelGGL(k_k1p_b2, dim3(n_slices), dim3(256), 0, s, p, status, st, en, tot);
     hipLaunchKernelGGL(k_k1p_zero, dim3(n_slices), dim3(256), 0, s, p, tot, S);
     hipLaunchKernelGGL(k_k1p_c, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
-    hipLaunchKernelGGL(k_k1p_d, dim3(n_slices), dim3(256), 0, s, p, tot, S, out, out_off, out_len, status);
+    uint32_t force_retry_every = 0;                              // test switch, see k_k1p_d
+    if (const char *f = getenv("AVR_K1P_FORCE_RETRY")) force_retry_every = uint32_t(strtoul(f, nullptr, 10));
+    hipLaunchKernelGGL(k_k1p_d, dim3(n_slices), dim3(256), 0, s, p, tot, S, out, out_off, out_len, status, force_retry_every);
+    return hipGetLastError();
+}
+
+hipError_t launch_cabac_encode_codes(hipStream_t s, const uint8_t *codes, const uint64_t *res_off, const uint32_t *n_bins,
+                                     const uint32_t *order, uint32_t n_slices, uint8_t *out, const uint64_t *out_off,
+                                     uint32_t *out_len, int32_t *status, int32_t want_status) {
+    if (n_slices == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cabac_encode_codes, dim3((n_slices + 63) / 64), dim3(64), 0, s, codes, res_off, n_bins, order, n_slices,
+                       out, out_off, out_len, status, want_status);
     return hipGetLastError();
 }
 
 static inline uint64_t resolve_ws_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl) {
-    return up256(pl->res_total + 32) + up256(uint64_t(pl->total_blocks) * n_states * 4 + 16) +
-           up256(n_slices * uint64_t(n_states + 1) * 4 + 16) + up256(uint64_t(pl->total_chunks) * sizeof(Seg)) +
-           up256(uint64_t(pl->total_chunks) + 16) + up256(uint64_t(pl->total_blocks) * n_states * 16 + 16) +
-           up256(uint64_t(pl->total_chunks) * ((n_states + 3) / 4) * 4 + 16);
+    return resolve_layout(n_slices, n_states, pl).total;
 }
 
 size_t k1p_code_workspace_bytes(size_t n_slices, const avr_chunk_plan *pl);
@@ -923,7 +1089,7 @@ hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
     uint8_t *w = static_cast<uint8_t *>(workspace);
     uint8_t *res = w;                                        w += up256(pl->res_total + 32);
     const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
-                 pl->dig_off, n_states};
+                 pl->dig_off, 0, n_states, nullptr, nullptr};
     hipError_t e = launch_resolve(s, p, n_slices, init_states, pl, w, res, status, final_states);
     if (e != hipSuccess) return e;
     w += resolve_ws_bytes(n_slices, n_states, pl);
@@ -943,11 +1109,11 @@ hipError_t launch_k1p_resolve(hipStream_t s, const uint16_t *recs, const uint64_
                               void *workspace, uint8_t *codes, int32_t *status, uint8_t *final_states) {
     if (n_slices == 0) return hipSuccess;
     const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
-                 pl->dig_off, n_states};
+                 pl->dig_off, 0, n_states, nullptr, nullptr};
     return launch_resolve(s, p, n_slices, init_states, pl, static_cast<uint8_t *>(workspace), codes, status, final_states);
 }
-// ... and phases B-D from resolved codes (no stretch is ever declined here: there are no records to
-// fall back to, so a stretch without an LPS is simply walked to its end by one lane)
+// ... and phases B-D from resolved codes (no stretch is declined for its length here: a stretch without an
+// LPS is simply walked to its end by one lane); a slice phase D hands back is coded by k_cabac_encode_codes
 size_t k1p_code_workspace_bytes(size_t n_slices, const avr_chunk_plan *pl) {
     return size_t(up256(uint64_t(pl->total_chunks) * sizeof(Stretch)) + up256(uint64_t(pl->total_chunks) * sizeof(Entry)) +
                   up256(n_slices * sizeof(SliceTotals)) + up256(pl->dig_total * 4 + 16));
@@ -957,8 +1123,11 @@ hipError_t launch_k1p_code(hipStream_t s, const uint8_t *codes, const uint32_t *
                            uint32_t *out_len, int32_t *status) {
     if (n_slices == 0) return hipSuccess;
     const Plan p{nullptr, nullptr, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
-                 pl->dig_off, 0};
-    return launch_code(s, p, n_slices, pl, static_cast<uint8_t *>(workspace), codes, 0xffffffffu, out, out_off, out_len, status);
+                 pl->dig_off, 0, 0, nullptr, nullptr};
+    hipError_t e = launch_code(s, p, n_slices, pl, static_cast<uint8_t *>(workspace), codes, 0xffffffffu, out, out_off, out_len, status);
+    if (e != hipSuccess) return e;
+    return launch_cabac_encode_codes(s, codes, pl->res_off, n_bins, nullptr, n_slices, out, out_off, out_len, status,
+                                     AVR_SLICE_RETRY_SERIAL);
 }
 
 }  // namespace avr

@@ -77,7 +77,10 @@ struct CabacLane {
         // hipcc sinks each read into a branch on the bin kind (it is only "needed" on one side of
         // a select), which splits the wave and exposes the full LDS latency behind every branch.
         asm volatile("" : "+v"(s_mem));
-        const uint32_t s = is_ctx ? (s_mem & 127u) : (2 * sel - 1920);   // 1024 -> 128, 1025 -> 130, 1026 -> 132
+        // 1024 -> 128, 1025 -> 130, 1026 and anything that is no context of the slice -> 132 (| bin: rows 132 and 133 are
+        // both "LPS range 0", and with valMPS = bin the symbol is 0, so such a record changes nothing whatever its bin)
+        const uint32_t t = min(2 * sel - 1920, 132u);
+        const uint32_t s = is_ctx ? (s_mem & 127u) : (t | ((t >> 2) == 33u ? rec & 1u : 0u));
         uint2 ent = tab[s];
         asm volatile("" : "+v"(ent.x), "+v"(ent.y));
         // normalize = floor(log2(range / 0x100)) (cabac_code.h:37,59,70-79); range != 0 here

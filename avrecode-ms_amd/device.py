@@ -283,6 +283,15 @@ class DeviceWorkload:
             ctypes.byref(p["plan"]), (p["ws2"].data_ptr() + 255) // 256 * 256, p["ws2_bytes"], self.out.data_ptr(),
             self.out_off.data_ptr(), self.out_len.data_ptr(), self.status.data_ptr()))
 
+    def encode_codes_serial(self, codes):
+        """K1 from resolved codes with one lane per slice (k_cabac_encode_codes): same bytes as encode()."""
+        import torch
+        p = self._chunk_plan()
+        _check(lib().avr_cabac_encode_codes_device(
+            self.device_index, _stream_ptr(torch), codes.data_ptr(), p["tensors"]["res_off"].data_ptr(), self.n_bins.data_ptr(),
+            self.order.data_ptr(), self.n_slices, self.out.data_ptr(), self.out_off.data_ptr(), self.out_len.data_ptr(),
+            self.status.data_ptr()))
+
     def encode_slice_major(self):
         """Same result from the slice-major layout (only for workloads built with from_host)."""
         import torch

@@ -122,8 +122,17 @@ def cpu_baseline(avr, workload, kind, n_slices, first_slice, gpu_bytes_of, budge
     bytes1 = sum(len(b) for b in cpu_bytes[:m1])
     gpu = gpu_bytes_of(m)
     parity = "bit-exact" if gpu == cpu_bytes else "MISMATCH"
+    cpu_model, sockets = "unknown", 0
+    try:
+        info = open("/proc/cpuinfo").read()
+        names = [l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("model name")]
+        cpu_model = names[0] if names else "unknown"
+        sockets = len({l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("physical id")}) or 1
+    except OSError:
+        pass
     return {
         "value": total / best, "unit": "bytes/s", "cores": cores, "kind": kind_name,
+        "cpu_model": cpu_model, "sockets": sockets,
         "sample": f"first {m} of {n_slices} slices of the same workload ({int(nb.astype(np.int64).sum())} bins, "
                   f"{total} H.264 bytes), best of <=3, one slice per task",
         "single_thread_value": bytes1 / dt1,
@@ -179,14 +188,25 @@ def main():
     first = shard_first_slice(rank, n_slices)
     w = avr.DeviceWorkload.synth(args.workload, n_slices, kind, local_rank, 1000, first)
     declared_states = w.n_states
-    if kind == avr.KIND_CABAC and not args.full_context_table:
-        w.densify()
 
     path = args.path
     if path == "auto":        # one lane per slice needs >= ~64 slices per SIMD-wave-slot to fill 256 CUs
         path = "chunked" if (kind == avr.KIND_CABAC and n_slices <= 32768 and w.total_bins // max(n_slices, 1) >= 8192) else "serial"
     if kind != avr.KIND_CABAC:
         path = "serial"
+    # The step contains everything a batch needs.  The intra-slice parallel kernels renumber the batch onto the
+    # contexts it uses inside their own histogram pass (nothing happens outside the step).  The one-lane-per-slice
+    # kernel wants the dense numbering in its records: there the renumbering (census + in-place remap + state
+    # gather) runs before the first step and is timed on its own -- its time is ADDED to every step below.
+    prepass_ms = 0.0
+    if kind == avr.KIND_CABAC and path == "serial" and not args.full_context_table:
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        w.densify()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        prepass_ms = e0.elapsed_time(e1)
     step = w.encode_chunked if path == "chunked" else w.encode
     if args.records == "resolved":
         if kind != avr.KIND_CABAC:
@@ -212,9 +232,11 @@ def main():
         step()
         ends[i].record()
     sync_all()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / max(args.steps, 1)
+    # the per-batch renumbering of the serial path (measured once above) belongs to every step
+    elapsed = time.perf_counter() - t0 + 1e-3 * prepass_ms * args.steps
+    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / max(args.steps, 1) + prepass_ms
 
+    failed = False
     out_bytes = w.output_bytes()
     status_bad = int((w.status != 0).sum().item())
     t_max, total_bytes = reduce_timing(dist if world > 1 else None, elapsed, out_bytes * args.steps, red_dev)
@@ -244,12 +266,13 @@ def main():
                        "layout": "slice-major" if path == "chunked" else "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("K1p: k_k1p_{hist,scan,scatter,spec,link,chain,replay,b1,b2,zero,c,d} (one step = 13 launches; "
-                                    "largest: k_k1p_scatter)" if path == "chunked" else "k_cabac_encode<tiled>")
+                         "kernel": ("K1p: k_k1p_{hist,densemap,scan,scatter,spec,link,chain,entry,replay,b1,b2,zero,c,d} (one step = "
+                                    "all of them; largest: k_k1p_scatter)" if path == "chunked" else "k_cabac_encode<tiled>")
                          if kind == avr.KIND_CABAC else "k_range_encode<tiled>",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
                          "bins_per_s": w.total_bins / (kernel_ms * 1e-3)},
             "slice_status_errors": status_bad,
+            "prepass_ms_in_step": prepass_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
             def gpu_bytes_of(m):
@@ -257,9 +280,13 @@ def main():
             line["cpu_baseline"] = cpu_baseline(avr, args.workload, kind, n_slices, first, gpu_bytes_of)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
+        if status_bad or line.get("cpu_baseline", {}).get("parity_vs_gpu") == "MISMATCH":
+            failed = True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("bench.py: GPU output differs from the CPU checker, or a slice came back with an error status")
 
 
 if __name__ == "__main__":

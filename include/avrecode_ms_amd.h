@@ -62,11 +62,6 @@ extern "C" {
 #define AVR_SLICE_ZERO_PROB   1  /* arithmetic_code.h:116-118 "emitted a zero-probability symbol" */
 #define AVR_SLICE_OVERFLOW    2  /* output region too small (never with the batch API's sizing) */
 #define AVR_SLICE_BAD_RECORD  3  /* selector out of range, or a bin after put_terminate(1) */
-#define AVR_SLICE_NOT_CODED   100 /* only from the resolved-code entry points (avr_cabac_encode_resolved_device,
-                                   * avr_batch_add_slice_codes): the parallel scheme met a carry pattern it does not
-                                   * resolve (two overlapping windows and 33 particular digits; not observed) and
-                                   * there are no records to recode the slice from.  With records the serial kernel
-                                   * recodes such a slice in the same call and the status stays 0. */
 
 #define AVR_SEL_BYPASS     1024
 #define AVR_SEL_TERMINATE  1025
@@ -119,7 +114,9 @@ int avr_batch_add_slice_range(avr_batch *b, const uint16_t *recs, size_t n);
  * as it is when the bin is requested, which the adapter holds anyway (it updates it, cabac_code.h:43-47) --
  * AVR_CODE_BYPASS(bin) or AVR_CODE_TERMINATE(bin): the (symbol, *state) pairs cabac::encoder::put takes
  * (cabac_code.h:33).  Half the bytes of avr_batch_add_slice_cabac over PCIe, no state arrays, and the
- * context-state resolution on the GPU is skipped.  put_terminate(1), if present, must be the last bin. */
+ * context-state resolution on the GPU is skipped.  put_terminate(1), if present, must be the last bin.
+ * A batch of few, long slices is coded by the intra-slice parallel kernels (K1p phases B-D), a batch of
+ * many short ones by one lane per slice (k_cabac_encode_codes); either way every slice is coded. */
 int avr_batch_add_slice_codes(avr_batch *b, const uint8_t *codes, size_t n);
 
 int avr_batch_run(avr_batch *b);
@@ -225,7 +222,12 @@ int avr_cabac_encode_chunked_device(int device, void *stream,
  * Stage 2, avr_cabac_encode_resolved_device: the arithmetic coding (phases B-D) from resolved codes.
  * A hook adapter that tracks *state itself -- it has to keep libavcodec's state bytes current anyway,
  * cabac_code.h:43-47 -- can record resolved codes directly with the AVR_CODE_* macros and skip stage 1.
- * The plan is the one of avr_cabac_encode_chunked_device (blk_* unused by stage 2). */
+ * The plan is the one of avr_cabac_encode_chunked_device (blk_* unused by stage 2).  A slice whose digit
+ * sums phase D does not resolve in parallel (a carry of two or more into a 33-digit segment of the form
+ * ffff ... fffe) is coded by the serial kernel below in the same call: every slice comes back coded.
+ *
+ * avr_cabac_encode_codes_device: the serial form, one lane per slice straight from the codes (no plan, no
+ * workspace): for batches of many short slices.  order may be NULL (else: slices taken longest first). */
 #define AVR_CODE_CONTEXT(state, bin)  ((state) >= 126 ? 255 - (((bin) ^ (state)) & 1) : (((state) << 1) | (bin)))
 #define AVR_CODE_BYPASS(bin)          (252 | (bin))
 #define AVR_CODE_TERMINATE(bin)       (255 - (bin))
@@ -242,6 +244,11 @@ int avr_cabac_encode_resolved_device(int device, void *stream,
                                      const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes,
                                      uint8_t *out, const uint64_t *out_off,
                                      uint32_t *out_len, int32_t *status);
+
+int avr_cabac_encode_codes_device(int device, void *stream,
+                                  const uint8_t *codes, const uint64_t *res_off, const uint32_t *n_bins,
+                                  const uint32_t *order, size_t n_slices,
+                                  uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status);
 
 /* Variants that read the slice-major layout directly (one 16-byte load per lane per 8 bins,
  * uncoalesced across lanes); kept for the layout comparison in DESIGN.md and for tests.  The

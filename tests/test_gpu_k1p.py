@@ -225,3 +225,76 @@ def test_dense_context_ids_change_nothing_but_the_numbering(avr, oracle, workloa
     got, status = w.results()
     assert not any(status) and got == want
     assert torch.equal(w.final_states_full(), fs)
+
+
+def _codes_of(avr, recs, st):
+    """What a hook adapter records per bin: AVR_CODE_CONTEXT / _BYPASS / _TERMINATE (include/avrecode_ms_amd.h)."""
+    _, mlps = avr.cabac_tables()
+    state = [int(x) for x in st]
+    out = np.zeros(recs.size, np.uint8)
+    for j, r in enumerate(recs):
+        b, sel = int(r) & 1, int(r) >> 1
+        if sel < 1024:
+            s = state[sel]
+            out[j] = 255 - ((b ^ s) & 1) if s >= 126 else (s << 1) | b
+            state[sel] = mlps[127 - s] if b != (s & 1) else mlps[128 + s]
+        else:
+            out[j] = (252 | b) if sel == 1024 else 255 - b
+    return out
+
+
+def test_serial_codes_kernel_equals_stage2_and_oracle(avr, oracle):
+    """k_cabac_encode_codes (one lane per slice from resolved codes) against phases B-D and the oracle."""
+    w = avr.DeviceWorkload.synth(2, 70, 0, 0, 40)
+    w.encode()
+    want, _ = w.results()
+    codes = w.resolve()
+    w.out.zero_(); w.out_len.zero_()
+    w.encode_codes_serial(codes)
+    got, status = w.results()
+    assert not any(status) and got == want
+    cfg, nb, off, recs, states = host_synth(avr, 2, 70, 0, 40)
+    assert got == oracle.encode_batch(0, *compact(recs, off, nb), states, cfg.n_states, threads=8)[0]
+
+
+@pytest.mark.parametrize("every", [1, 3])
+def test_phase_d_hand_over_is_coded_by_the_serial_kernels(avr, oracle, monkeypatch, every):
+    """Phase D hands a slice whose carries it does not resolve in parallel to a serial kernel.  The pattern (a
+    carry >= 2 into a 33-digit segment ffff...fffe) does not occur in practice, so the test switch
+    AVR_K1P_FORCE_RETRY makes phase D hand over every n-th slice: the bytes must still be the oracle's, from
+    records (k_cabac_encode) and from resolved codes (k_cabac_encode_codes), with status 0 everywhere."""
+    monkeypatch.setenv("AVR_K1P_FORCE_RETRY", str(every))
+    rng = np.random.default_rng(31 + every)
+    slices = [oracle_lib.random_cabac_stream(rng, int(rng.integers(1, 30000)), 120, terminate=bool(i % 3)) for i in range(20)]
+    want = [oracle.cabac_encode(r, s) for r, s in slices]
+    w = avr.DeviceWorkload.from_host(0, [r for r, _ in slices], [s for _, s in slices], 0)
+    w.encode_chunked()                                       # records: phase A .. D, then k_cabac_encode
+    got, status = w.results()
+    assert not any(status) and got == [x[0] for x in want]
+    codes = w.resolve()
+    w.out.zero_(); w.out_len.zero_()
+    w.encode_resolved(codes)                                 # codes: phases B .. D, then k_cabac_encode_codes
+    got, status = w.results()
+    assert not any(status) and got == [x[0] for x in want]
+    # and through the batch API (what the host decompressor uses)
+    monkeypatch.setenv("AVR_K1_PATH", "chunked")
+    with avr.Batch(0, len(slices), sum(len(r) for r, _ in slices) + 64) as b:
+        for r, s in slices:
+            b.add_codes(_codes_of(avr, r, s))
+        b.run()
+        for i in range(len(slices)):
+            assert b.get(i) == (want[i][0], 0), f"slice {i}"
+
+
+def test_batch_of_many_short_slices_from_codes(avr, oracle):
+    """10 000 short slices of resolved codes: the batch takes the one-lane-per-slice kernel (no per-chunk
+    machinery), inside the limits the caller declared (max_bins = the exact total)."""
+    rng = np.random.default_rng(9)
+    slices = [oracle_lib.random_cabac_stream(rng, int(rng.integers(0, 40)), 30, terminate=bool(i % 2)) for i in range(10000)]
+    total = sum(len(r) for r, _ in slices)
+    with avr.Batch(0, len(slices), total) as b:
+        for r, s in slices:
+            b.add_codes(_codes_of(avr, r, s))
+        b.run()
+        for i, (r, s) in enumerate(slices):
+            assert b.get(i) == (oracle.cabac_encode(r, s)[0], 0), f"slice {i}"
