@@ -587,8 +587,8 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
     uint32_t *T = replay_lds;
     const uint32_t lane = threadIdx.x & 63, nk = p.n_states;
     uint8_t *stb = reinterpret_cast<uint8_t *>(replay_lds + kReplayTable) + (threadIdx.x >> 6) * (((nk + 8) >> 2) << 8) + lane * 4;
-    for (uint32_t k = threadIdx.x; k < 1024; k += 256) tab[k] = p.table[k];
-    for (uint32_t st = threadIdx.x; st < kReplayTable; st += 256) {
+    for (uint32_t k = threadIdx.x; k < 1024; k += blockDim.x) tab[k] = p.table[k];
+    for (uint32_t st = threadIdx.x; st < kReplayTable; st += blockDim.x) {
         uint32_t e;
         if (st < 128) e = d_tables.packed[st][1] | code_context(st, 0) << 16 | code_context(st, 1) << 24;
         else {
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
         T[st] = e;
     }
     __syncthreads();
-    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t gc = blockIdx.x * blockDim.x + threadIdx.x;
     if (gc >= total_chunks) return;
     const uint32_t s = p.chunk_slice[gc];
     if (status[s] != AVR_SLICE_OK) return;
@@ -1035,12 +1035,16 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
         hipLaunchKernelGGL(k_k1p_entry, dim3((pl->total_chunks + cpb - 1) / cpb), dim3(256), 0, s, p, pl->total_chunks, status, qoff,
                            sorted, init_states, est, cpb, (65536 + nkw - 1) / nkw);
     }
-    const uint32_t replay_lds = kReplayTable * 4 + 4 * ((n_states + 8) / 4) * 256;
-    if (replay_lds > 64 * 1024) {
+    // the waves of a workgroup share the two tables; each has its own state rows: as many waves as 60 KiB hold (1 .. 4)
+    const uint32_t per_wave = ((n_states + 8) / 4) * 256;
+    const uint32_t replay_waves = per_wave * 4 <= 60 * 1024 ? 4 : per_wave * 2 <= 60 * 1024 ? 2 : 1;
+    const uint32_t replay_lds = kReplayTable * 4 + replay_waves * per_wave;
+    if (replay_lds > 60 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_k1p_replay), hipFuncAttributeMaxDynamicSharedMemorySize, int(replay_lds));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_k1p_replay, dim3(chunk_blocks), dim3(256), replay_lds, s, p, pl->total_chunks, est, res, status);
+    hipLaunchKernelGGL(k_k1p_replay, dim3((pl->total_chunks + 64 * replay_waves - 1) / (64 * replay_waves)), dim3(64 * replay_waves),
+                       replay_lds, s, p, pl->total_chunks, est, res, status);
     return hipGetLastError();
 }
 
