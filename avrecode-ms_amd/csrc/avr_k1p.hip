@@ -53,20 +53,39 @@ struct Plan {                       // device pointers of the caller's plan (avr
 constexpr uint32_t kNotUsed = 0xffffu;
 
 // ------------------------------------------------------------------ phase A
+//
+// Context states evolve per context, independent of low / range (cabac_code.h:43-47): the state a bin is
+// coded in is a function of the bins the same context coded before it.  A slice is cut into chunks of
+// kChunk bins; what phase A has to find is the state of every context at the start of every chunk
+// (`est`), from which one lane per chunk replays its bins in stream order (k_k1p_replay).
+//
+//   k_k1p_census    workgroup per 4096 bins   validates every record; which contexts the batch uses
+//   k_k1p_densemap  one workgroup             dense numbering of those contexts
+//   k_k1p_local     lane per chunk            counting sort of the chunk's bins by context, lane-serial: per
+//                                             context the number of bins, and the bins themselves as a bit string
+//   k_k1p_ctxchain  lane per (slice, context) the context's state chain through the slice, chunk by chunk over
+//                                             those bit strings, eight bins per table look-up -> est
+//   k_k1p_replay    lane per chunk            resolved code of every bin, in stream order
+//
+// Why this shape.  A 1080p stream spreads its bins over ~90 contexts, the hottest of which gets 5 % of them:
+// about 50 bins of a 1024-bin chunk, far too few for any shortcut through the state machine, so each
+// context's bins have to be walked in order -- the chain is serial per (slice, context), 512 x 86 of them in
+// BASELINE.json's configs[1], and short per chunk.  What it needs is every context's bins side by side:
+// a sort by context.  Round 1 sorted whole slices (a wave ranks 64 bins with one ballot per key bit: 1.1
+// vector instructions per bin, three passes over the records, four more over the sorted copy).  Sorting
+// inside the chunk instead lets ONE LANE do it with private counters in LDS -- a count pass and a
+// placement pass of a dozen instructions per bin at full SIMD width, no cross-lane ranking at all -- and
+// the result is tiny: 1024 bits and one 16-bit end position per context per chunk.
 
 // Also the one place every record of this path is examined: a selector that is no context of the
 // slice, bypass or terminate, or a bin after put_terminate(1), flags the slice AVR_SLICE_BAD_RECORD.
-//
-// Contexts are counted under the caller's numbering (the offset of the state byte in cabac_state[],
-// recode.cpp:325: up to 1024, of which a stream touches few).  The census of the contexts the batch
-// uses falls out of the same pass -- the non-zero columns -- as a 1024-bit map; k_k1p_densemap turns it
-// into the dense numbering every later kernel sorts and indexes by, applied to the records as they are
-// loaded (one LDS look-up), so no pass over the records exists for the renumbering.
-__global__ __launch_bounds__(256) void k_k1p_hist(Plan p, int32_t *status, uint16_t *hist16, uint32_t *used) {
-    __shared__ uint32_t cnt[AVR_MAX_STATES];
+// Contexts are identified under the caller's numbering (the offset of the state byte in cabac_state[],
+// recode.cpp:325: up to 1024, of which a stream touches few); `used` gets one bit per context that occurs.
+__global__ __launch_bounds__(256) void k_k1p_census(Plan p, int32_t *status, uint32_t *used) {
+    __shared__ uint8_t flag[AVR_MAX_STATES];
     __shared__ uint32_t bm[32];
     const uint32_t b = blockIdx.x, s = p.blk_slice[b], nk = p.ns_full;
-    for (uint32_t k = threadIdx.x; k < nk; k += 256) cnt[k] = 0;
+    for (uint32_t k = threadIdx.x; k < AVR_MAX_STATES / 4; k += 256) reinterpret_cast<uint32_t *>(flag)[k] = 0;
     if (threadIdx.x < 32) bm[threadIdx.x] = 0;
     __syncthreads();
     if (status[s] == AVR_SLICE_OK) {
@@ -85,7 +104,7 @@ __global__ __launch_bounds__(256) void k_k1p_hist(Plan p, int32_t *status, uint1
             for (uint32_t j = 0; j < 8; j++) {
                 const uint32_t rec = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu, sel = rec >> 1;   // sel keeps bits 12..15: a set one is bad too
                 if (i + j < i1) {
-                    if (sel < nk) atomicAdd(&cnt[sel], 1u);
+                    if (sel < nk) flag[sel] = 1;                 // plain store: every writer writes the same value
                     else {
                         const uint32_t t = rec - 2048u + (i + j + 1 == n ? 0u : (rec == 2051u ? 4u : 0u));
                         worst = worst > t ? worst : t;
@@ -97,10 +116,10 @@ __global__ __launch_bounds__(256) void k_k1p_hist(Plan p, int32_t *status, uint1
         if (bad) status[s] = AVR_SLICE_BAD_RECORD;
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < nk; k += 256) {
-        const uint32_t c = cnt[k];
-        hist16[size_t(b) * nk + k] = uint16_t(c);                // <= kSortBlock
-        if (c) atomicOr(&bm[k >> 5], 1u << (k & 31));
+    {
+        const uint32_t f = reinterpret_cast<const uint32_t *>(flag)[threadIdx.x];          // contexts 4t .. 4t+3
+        const uint32_t nib = (f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u);
+        if (nib) atomicOr(&bm[threadIdx.x >> 3], nib << ((threadIdx.x & 7) * 4));
     }
     __syncthreads();
     // bits only ever get set, so a (possibly stale) plain read tells which are still missing: after the
@@ -130,455 +149,226 @@ __global__ __launch_bounds__(1024) void k_k1p_densemap(const uint32_t *used, uin
     if (k == 1023) *n_dense = sc[1023];
 }
 
-// hist16[b][caller's number] -> boff[b][k] = position (within the slice's sorted order) of the first bin of
-// context k (dense) in block b; run_start[s][k] = first position of context k, run_start[s][nk] = number of
-// context bins.
-__global__ __launch_bounds__(1024) void k_k1p_scan(Plan p, const uint16_t *hist16, uint32_t *boff, uint32_t *run_start) {
-    __shared__ uint32_t sc[1024];
-    const uint32_t s = blockIdx.x, k = threadIdx.x, nk = p.n_states, ns = p.ns_full;
-    const uint32_t b0 = p.blk_base[s], b1 = p.blk_base[s + 1];
-    const uint32_t col = k < nk ? p.index[k] : 0;
-    uint32_t total = 0;
-    if (k < nk) {
-        uint32_t b = b0;
-        for (; b + 8 <= b1; b += 8) {                            // eight loads in flight: the loop is their latency
-            uint32_t c[8];
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) c[j] = hist16[size_t(b + j) * ns + col];
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) total += c[j];
-        }
-        for (; b < b1; b++) total += hist16[size_t(b) * ns + col];
+// State after n = 0 .. 8 bins, per state and bin pattern (first bin in the low bit; cabac_code.h:43-47):
+//   tn[(128 << n) - 128 + (st << n | bits)],  bits < 2^n                           (kTnBytes in all)
+constexpr uint32_t kTnBytes = 128 * 511;
+__global__ __launch_bounds__(256) void k_k1p_tn(uint8_t *tn) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kTnBytes) return;
+    const uint32_t n = 31 - __clz((i >> 7) + 1), j = i - ((128u << n) - 128u);
+    uint32_t st = j >> n;
+    for (uint32_t b = 0; b < n; b++) {
+        const uint32_t nx = d_tables.packed[st][1], bin = (j >> b) & 1u;
+        st = ((bin ^ st) & 1u) ? (nx >> 8) & 0xffu : nx & 0xffu;
     }
-    sc[k] = total;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {                    // inclusive scan over contexts
-        const uint32_t v = k >= d ? sc[k - d] : 0;
-        __syncthreads();
-        sc[k] += v;
-        __syncthreads();
-    }
-    uint32_t run = sc[k] - total;                                // exclusive
-    if (k < nk) {
-        run_start[size_t(s) * (nk + 1) + k] = run;
-        uint32_t b = b0;
-        for (; b + 8 <= b1; b += 8) {
-            uint32_t c[8];
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) c[j] = hist16[size_t(b + j) * ns + col];
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) { boff[size_t(b + j) * nk + k] = run; run += c[j]; }
-        }
-        for (; b < b1; b++) {
-            const uint32_t c = hist16[size_t(b) * ns + col];
-            boff[size_t(b) * nk + k] = run;
-            run += c;
-        }
-    }
-    if (k == 1023) run_start[size_t(s) * (nk + 1) + nk] = sc[1023];
+    tn[i] = uint8_t(st);
 }
 
-// One workgroup of 4 waves per sort block; wave w takes the w-th quarter of the block.  Bins are
-// taken 64 at a time in stream order; the lanes holding the same context find each other with one
-// ballot per key bit, which gives every bin its rank among them (stable), and the first of them
-// advances the context's running position.  A wave is a serial chain through those running
-// positions, so the block is quartered to shorten it: the quarters are counted first (LDS atomics),
-// each wave starts from the block's local start of the context plus what the quarters before it hold.
+// One lane per chunk: counting sort of the chunk's context bins by (dense) context, in LDS, serially.
+//   pass 1  count the bins of every context                    cnt[k][lane]++           (16-bit, lane-private)
+//   scan    exclusive prefix over the contexts                 cnt[k][lane] = first position of context k
+//   pass 2  place: position = cnt[k][lane]++, the bin goes to bit `position` of the lane's 1024-bit string
+// after which cnt[k][lane] is where context k's bins END (context k's bins are bits [end[k-1], end[k])).
+// Out: lbits[gc][32 dwords], lend[gc][nk] (16-bit), both written through a transposed read of the LDS
+// arrays so that a wave's stores are contiguous.
 //
-// The block is sorted into LDS first and copied out afterwards: its bins of one context go to
-// consecutive global positions, so the copy-out stores are runs of consecutive bytes, where a
-// direct scatter would be 64 different cache lines per store instruction (measured: the direct
-// form spent 75 % of its wave cycles stalled on issuing those stores).
-constexpr uint32_t kQuarter = kSortBlock / 4, kQuarterBatches = kQuarter / 64;
-
-template <uint32_t KEY_BITS>
-__global__ __launch_bounds__(256, 8) void k_k1p_scatter(Plan p, const int32_t *status, const uint32_t *boff,
-                                                     const uint32_t *run_start, uint8_t *sorted, uint32_t *qoff) {
-    // LDS (dynamic, sized by the number of contexts so that more blocks fit a CU):
-    extern __shared__ uint32_t scatter_lds[];
-    const uint32_t nk = p.n_states, nk_pad = (nk + 63) & ~63u;
-    uint32_t *cnt = scatter_lds;                                 // [4][nk_pad]: next local position, per wave
-    uint32_t *delta = cnt + 4 * nk_pad;                          // global position - local position
-    uint16_t *kbuf = reinterpret_cast<uint16_t *>(delta + nk_pad);   // context of every locally sorted bin
-    uint8_t *lbuf = reinterpret_cast<uint8_t *>(kbuf + kSortBlock);  // the bins, locally sorted
-    __shared__ uint16_t tab[1024];                               // caller's context number -> dense id
-    __shared__ uint32_t sh_n_local;
-    const uint32_t b = blockIdx.x, s = p.blk_slice[b], t = threadIdx.x, lane = t & 63, w = t >> 6;
-    if (status[s] != AVR_SLICE_OK) return;
-    const uint32_t n = p.n_bins[s], i0 = (b - p.blk_base[s]) * kSortBlock;
-    const uint32_t i1 = i0 + kSortBlock < n ? i0 + kSortBlock : n;
-    const uint16_t *r = p.recs + p.rec_off[s];
-    // this wave's records: batch j of the quarter is r[q0 + 64 j + lane]
-    const uint32_t q0 = i0 + w * kQuarter;
-    uint32_t recs[kQuarterBatches];
-    const uint16_t *rq = r + q0 + lane;
-    if (q0 + kQuarter <= i1) {                                   // a whole quarter (all but a slice's last block): no bounds to check
-#pragma unroll
-        for (uint32_t j = 0; j < kQuarterBatches; j++) recs[j] = rq[64 * j];
-    } else {
-#pragma unroll
-        for (uint32_t j = 0; j < kQuarterBatches; j++) recs[j] = q0 + 64 * j + lane < i1 ? rq[64 * j] : uint32_t(AVR_NOP_CABAC);
+// The counters of contexts 2j and 2j+1 share a dword (a chunk has at most 1024 bins: no carry from the low
+// half), and every update is an LDS atomic on the lane's own dword: ds_add_u32 without return in pass 1,
+// ds_add_rtn_u32 in pass 2, ds_or_b32 for the bit.  Nothing else touches those dwords, so "atomic" only means
+// that the LDS does the read-modify-write itself, in issue order: the eight bins of a 16-byte group are
+// eight independent instructions in flight, where a load / add / store per bin is a chain of LDS round
+// trips (the compiler must keep them in order: two bins of a group may hit the same counter).
+// Row j of `cnt` and row j of `bits` are 64 lanes wide: the data-dependent accesses never conflict across
+// lanes.  What a record's 11-bit selector means is one look-up: sel_tab[selector] = byte offset of the
+// counter row | 16 for the high half.  A bin that is no context bin (bypass, terminate, padding, a context
+// the batch does not use) counts into a spare row whose positions start at 1024, i.e. land in a spare row
+// of `bits`: no branch on the bin kind anywhere.
+__global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks, const int32_t *status, uint32_t *lbits,
+                                                   uint16_t *lend) {
+    extern __shared__ uint32_t local_lds[];                      // per wave: bits[33][64], then cnt[(nk + 2) / 2][64] (two 16-bit counters each)
+    __shared__ uint32_t sel_tab[2048];
+    const uint32_t nk = p.n_states, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t cnt_rows = (nk + 2) / 2;                      // contexts 0 .. nk-1 and the spare row nk
+    const uint32_t wave_dwords = (33 + cnt_rows) * 64;
+    uint32_t *bits = local_lds + wv * wave_dwords;
+    uint32_t *cnt = bits + 33 * 64;
+    for (uint32_t sel = threadIdx.x; sel < 2048; sel += blockDim.x) {
+        const uint32_t d = sel < 1024u ? uint32_t(p.table[sel]) : kNotUsed;
+        const uint32_t k = d < nk ? d : nk;
+        sel_tab[sel] = (k >> 1) * 256u | (k & 1u) * 16u;
     }
-    for (uint32_t k = t; k < 4 * nk_pad; k += 256) cnt[k] = 0;
-    for (uint32_t k = t; k < 1024; k += 256) tab[k] = p.table[k];
+    for (uint32_t i = lane; i < wave_dwords; i += 64) bits[i] = 0;
     __syncthreads();
-#pragma unroll
-    for (uint32_t j = 0; j < kQuarterBatches; j++) {             // renumber (dense ids), count the quarter
-        const uint32_t raw = (recs[j] >> 1) & 0x7ffu;
-        const uint32_t sel = raw < 1024u ? uint32_t(tab[raw]) : raw | 0x8000u;      // not a context: anything >= nk
-        recs[j] = (recs[j] & 1u) | (sel << 1);
-        if (sel < nk) atomicAdd(&cnt[w * nk_pad + sel], 1u);
-    }
-    __syncthreads();
-    if (w == 0) {
-        // local exclusive scan of the block's per-context counts: 16 consecutive contexts per lane
-        const bool last_block = b + 1 == p.blk_base[s + 1];
-        const uint32_t *g0 = boff + size_t(b) * nk;
-        const uint32_t *g1 = last_block ? run_start + size_t(s) * (nk + 1) + 1 : g0 + nk;   // where context k stops
-        uint32_t mine[16], sum = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 16; j++) {
-            const uint32_t k = lane * 16 + j;
-            mine[j] = k < nk ? g1[k] - g0[k] : 0;
-            sum += mine[j];
-        }
-        uint32_t incl = sum;
-        for (uint32_t d = 1; d < 64; d <<= 1) {
-            const uint32_t v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
-        }
-        uint32_t run = incl - sum;
-        if (lane == 63) sh_n_local = incl;                       // context bins in this block
-#pragma unroll
-        for (uint32_t j = 0; j < 16; j++) {
-            const uint32_t k = lane * 16 + j;
-            if (k < nk) {
-                delta[k] = g0[k] - run;
-                uint32_t at = run;                               // quarter w starts after the quarters before it
-                for (uint32_t q = 0; q < 4; q++) { const uint32_t c = cnt[q * nk_pad + k]; cnt[q * nk_pad + k] = at; at += c; }
-            }
-            run += mine[j];
+    const uint32_t gc0 = (blockIdx.x * (blockDim.x >> 6) + wv) * 64, gc = gc0 + lane;
+    uint32_t i0 = 0, i1 = 0;
+    const uint16_t *r = p.recs;
+    if (gc < total_chunks) {
+        const uint32_t s = p.chunk_slice[gc];
+        if (status[s] == AVR_SLICE_OK) {
+            const uint32_t n = p.n_bins[s];
+            i0 = (gc - p.chunk_base[s]) * kChunk;
+            i1 = i0 + kChunk < n ? i0 + kChunk : n;
+            if (i0 > i1) i0 = i1;
+            r = p.recs + p.rec_off[s];
         }
     }
-    __syncthreads();
-    // where every quarter's bins of every context start in the slice's sorted order (for k_k1p_replay)
-    for (uint32_t k = t; k < nk; k += 256) {
-        const uint32_t d = delta[k];
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) qoff[(size_t(b) * 4 + q) * nk + k] = cnt[q * nk_pad + k] + d;
-    }
-    __syncthreads();
-    uint32_t *my_cnt = cnt + w * nk_pad;
-    const uint64_t lt = (uint64_t(1) << lane) - 1;
-#pragma unroll
-    for (uint32_t j = 0; j < kQuarterBatches; j++) {
-        uint32_t rec = recs[j];
-        asm volatile("" : "+v"(rec));                            // keeps this batch's ballots here: hoisted to the top, the 16 x KEY_BITS
-                                                                 // lane masks outlive the SGPR file and are spilled (measured 1.45x slower)
-        const uint32_t sel = rec >> 1;
-        const bool is_ctx = sel < nk;
-        // lanes holding the same context: for every key bit keep the lanes whose bit equals mine,
-        // mask &= ~(ballot(bit) ^ (my bit ? ~0 : 0)), one three-input bit operation per half
-        const uint64_t m0 = __ballot(is_ctx);
-        uint32_t mask_lo = uint32_t(m0), mask_hi = uint32_t(m0 >> 32);
-#pragma unroll
-        for (uint32_t bit = 0; bit < KEY_BITS; bit++) {
-            const uint32_t mine = uint32_t(__builtin_amdgcn_sbfe(int32_t(rec), bit + 1, 1));   // bit of the selector, as 0 / ~0
-            const uint64_t m = __ballot(mine != 0);
-            mask_lo &= ~(uint32_t(m) ^ mine);
-            mask_hi &= ~(uint32_t(m >> 32) ^ mine);
-        }
-        const uint64_t mask = uint64_t(mask_lo) | uint64_t(mask_hi) << 32;
-        if (is_ctx) {
-            const uint32_t rank = __popcll(mask & lt);
-            const uint32_t start = my_cnt[sel];
-            const uint32_t at = start + rank;
-            lbuf[at] = uint8_t(rec & 1);
-            kbuf[at] = uint16_t(sel);
-            if (rank == 0) my_cnt[sel] = start + __popcll(mask);
-        }
-    }
-    __syncthreads();
-    uint8_t *so = sorted + p.res_off[s];
-    const uint32_t n_local = sh_n_local;
-    for (uint32_t j = t; j < n_local; j += 256) so[j + delta[kbuf[j]]] = lbuf[j];
-}
-
-// ---- A4: state chains over the sorted order.
-//
-// The bins of one context are a contiguous run of `sorted`, in stream order; the state before each
-// is a chain from the slice's initial state (cabac_code.h:43-47).  A hot context's run is tens of
-// thousands of bins long, so the sorted order is cut into SEGMENTS of kChunk positions, one lane
-// each.  A run that starts inside a segment starts from its known initial state.  For the run a
-// segment is entered in the middle of, the state is not known yet -- but the CABAC transition
-// functions are MONOTONE in the order
-//     (62,MPS 0) < (61,0) < ... < (0,0) < (0,1) < ... < (62,MPS 1)          [pStateIdx, valMPS]
-// (tests/test_k1p_emul.py checks this on the tables), so if the two extreme states 124 and 125
-// have reached the same state after some bins, every possible state has.  k_k1p_spec walks the
-// entered run from both extremes (and the run it is left in, exactly, if that run started inside);
-// k_k1p_link gives every segment its true entry state (replaying predecessors only where the
-// extremes did not meet, which real streams essentially never do over 1024 bins of one context);
-// k_k1p_chain walks every segment once more and writes the resolved codes.
-
-struct Seg {
-    uint32_t k_first;        // context whose run contains the segment's first position
-    uint16_t lo, hi;         // state at the segment's end of the run it is left in, from the extremes
-                             // 124 / 125 (equal: exact); only meaningful if that run goes on
-    uint8_t enters_mid;      // the first position is not the start of its run
-    uint8_t leaves_mid;      // the last position is not the end of its run
-    uint8_t empty;           // no positions
-    uint8_t pad;
-};
-
-__device__ __forceinline__ uint32_t chain_next(const uint32_t *next, uint32_t st, uint32_t bin) {
-    const uint32_t nx = next[st];
-    return ((bin ^ st) & 1) ? (nx >> 8) : (nx & 0xffu);
-}
-
-// Walk sorted positions [from, to) of one run.  WRITE: replace each bin by its resolved code.
-// Two states are carried (for the speculative walk); pass the same value twice for an exact walk.
-template <bool WRITE>
-__device__ __forceinline__ void chain_walk(const uint32_t *next, uint8_t *so, uint32_t from, uint32_t to,
-                                           uint32_t &a, uint32_t &b) {
-    uint32_t at = from;
-    auto one = [&](uint32_t bin) {
-        const uint32_t code = code_context(a, bin);
-        a = chain_next(next, a, bin);
-        if (!WRITE) b = chain_next(next, b, bin);
-        return code;
-    };
-    auto group16 = [&](U4 v, uint32_t where) {
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t sh = (j & 3) * 8;
-            const uint32_t code = one((w[j >> 2] >> sh) & 1u);
-            if (WRITE) w[j >> 2] = (w[j >> 2] & ~(0xffu << sh)) | (code << sh);
-        }
-        if (WRITE) *reinterpret_cast<U4 *>(so + where) = U4{w[0], w[1], w[2], w[3]};
-    };
-    for (; at < to && (at & 15); at++) { const uint32_t c = one(so[at]); if (WRITE) so[at] = uint8_t(c); }
-    for (; at + 16 <= to && (at & 63); at += 16) group16(*reinterpret_cast<const U4 *>(so + at), at);
-    for (; at + 64 <= to; at += 64) {                    // a whole cache line per lane per trip (see for_codes_all)
-        const U4 *p = reinterpret_cast<const U4 *>(so + at);
-        const U4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-        group16(v0, at); group16(v1, at + 16); group16(v2, at + 32); group16(v3, at + 48);
-    }
-    for (; at + 16 <= to; at += 16) group16(*reinterpret_cast<const U4 *>(so + at), at);
-    for (; at < to; at++) { const uint32_t c = one(so[at]); if (WRITE) so[at] = uint8_t(c); }
-}
-
-// context whose run [rs[k], rs[k+1]) contains sorted position `at` (at < rs[nk])
-__device__ __forceinline__ uint32_t run_of(const uint32_t *rs, uint32_t nk, uint32_t at) {
-    uint32_t lo = 0, hi = nk;                                    // invariant: rs[lo] <= at < rs[hi]
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (rs[mid] <= at) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-__global__ __launch_bounds__(256) void k_k1p_spec(Plan p, uint32_t total_chunks, const int32_t *status,
-                                                  const uint32_t *run_start, const uint8_t *init_states,
-                                                  uint8_t *sorted, Seg *seg) {
-    __shared__ uint32_t next[128];
-    if (threadIdx.x < 128) next[threadIdx.x] = d_tables.packed[threadIdx.x][1];
-    __syncthreads();
-    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
-    if (gc >= total_chunks) return;
-    const uint32_t s = p.chunk_slice[gc], nk = p.n_states;
-    Seg o{0, 0, 0, 0, 0, 1, 0};
-    const uint32_t *rs = run_start + size_t(s) * (nk + 1);
-    const uint32_t from = (gc - p.chunk_base[s]) * kChunk;
-    if (status[s] != AVR_SLICE_OK || from >= rs[nk]) { seg[gc] = o; return; }
-    const uint32_t to = from + kChunk < rs[nk] ? from + kChunk : rs[nk];
-    uint8_t *so = sorted + p.res_off[s];
-    const uint8_t *init = init_states + size_t(s) * p.ns_full;   // rows in the caller's numbering
-    const uint32_t k0 = run_of(rs, nk, from);
-    o.empty = 0;
-    o.k_first = k0;
-    o.enters_mid = rs[k0] < from;
-    const uint32_t k1 = run_of(rs, nk, to - 1);                 // the run the segment is left in
-    o.leaves_mid = rs[k1 + 1] > to;
-    if (o.leaves_mid) {
-        const uint32_t i0 = init[p.index[k1]] & 127u;
-        uint32_t a, b;
-        if (k1 == k0 && o.enters_mid && i0 < 126) { a = 124; b = 125; }        // entered and left in the same run
-        else a = b = i0;                                          // the run starts here, or its state never moves
-        if (i0 < 126) chain_walk<false>(next, so, k1 == k0 ? from : rs[k1], to, a, b);
-        o.lo = uint16_t(a);
-        o.hi = uint16_t(b);
-    }
-    seg[gc] = o;
-}
-
-// entry[gc] = state of the run the segment is entered in the middle of, at its first position.
-__global__ __launch_bounds__(256) void k_k1p_link(Plan p, uint32_t total_chunks, const int32_t *status,
-                                                  const uint32_t *run_start, const uint8_t *init_states,
-                                                  uint8_t *sorted, const Seg *seg, uint8_t *entry) {
-    __shared__ uint32_t next[128];
-    if (threadIdx.x < 128) next[threadIdx.x] = d_tables.packed[threadIdx.x][1];
-    __syncthreads();
-    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
-    if (gc >= total_chunks) return;
-    const Seg me = seg[gc];
-    if (me.empty || !me.enters_mid) { entry[gc] = 0; return; }
-    const uint32_t s = p.chunk_slice[gc];
-    // back to the nearest predecessor whose exit is known without its own entry
-    uint32_t j = gc - 1;                                         // c >= 1 because the segment is entered mid-run
-    while (seg[j].lo != seg[j].hi) j--;                          // ends at the latest where the run starts (exact walk)
-    uint32_t st = seg[j].lo;
-    if (j + 1 < gc) {                                            // replay the predecessors whose extremes did not meet
-        uint8_t *so = sorted + p.res_off[s];
-        for (uint32_t r = j + 1; r < gc; r++) {
-            const uint32_t from = (r - p.chunk_base[s]) * kChunk;
-            uint32_t a = st, b = st;
-            chain_walk<false>(next, so, from, from + kChunk, a, b);
-            st = a;
-        }
-    }
-    (void)run_start; (void)init_states; (void)status;
-    entry[gc] = uint8_t(st);
-}
-
-__global__ __launch_bounds__(256) void k_k1p_chain(Plan p, uint32_t total_chunks, const int32_t *status,
-                                                   const uint32_t *run_start, const uint8_t *init_states,
-                                                   uint8_t *sorted, const Seg *seg, const uint8_t *entry,
-                                                   uint8_t *final_states) {
-    __shared__ uint32_t next[128];
-    // two bins per look-up: pair[st] = { state after a first bin 0 | 1,  state after bins 00 | 01 | 10 | 11
-    // (first bin in the higher index bit) }: the walk is a chain of dependent LDS reads, this halves it
-    __shared__ uint2 pair[128];
-    if (threadIdx.x < 128) {
-        const uint32_t st = threadIdx.x, nx = d_tables.packed[st][1];
-        next[st] = nx;
-        uint32_t mid[2], end = 0;
-        for (uint32_t b0 = 0; b0 < 2; b0++) {
-            mid[b0] = ((b0 ^ st) & 1) ? (nx >> 8) : (nx & 0xffu);
-            const uint32_t n2 = d_tables.packed[mid[b0]][1];
-            for (uint32_t b1 = 0; b1 < 2; b1++) end |= (((b1 ^ mid[b0]) & 1) ? (n2 >> 8) : (n2 & 0xffu)) << (8 * (2 * b0 + b1));
-        }
-        pair[st] = make_uint2(mid[0] | mid[1] << 8, end);
-    }
-    __syncthreads();
-    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
-    if (gc >= total_chunks) return;
-    const uint32_t s = p.chunk_slice[gc], nk = p.n_states;
-    if (status[s] != AVR_SLICE_OK) return;
-    const uint32_t *rs = run_start + size_t(s) * (nk + 1);
-    // rows of init_states / final_states are in the caller's numbering; final_states starts out as a copy of
-    // init_states (launch_resolve), so only contexts that have bins in the slice are written here
-    const uint8_t *init = init_states + size_t(s) * p.ns_full;
-    uint8_t *fin = final_states ? final_states + size_t(s) * p.ns_full : nullptr;
-    const uint16_t *idx = p.index;
-    const uint32_t c = gc - p.chunk_base[s], from = c * kChunk;
-    const Seg me = seg[gc];
-    if (me.empty) return;
-    const uint32_t to = from + kChunk < rs[nk] ? from + kChunk : rs[nk];
-    uint8_t *so = sorted + p.res_off[s];
-    uint32_t k = me.k_first;
-    uint32_t st = me.enters_mid ? uint32_t(entry[gc]) : (init[idx[k]] & 127u);
-    uint32_t run_end = rs[k + 1];                                // > from: the segment's first position lies in run k
-    // run k ends at `run_end`: its final state, then on to the next run that has bins
-    auto next_run = [&]() {
-        if (fin) fin[idx[k]] = uint8_t(st);
-        k++;
-        while (k < nk && rs[k + 1] == rs[k]) k++;
-        if (k < nk) { st = init[idx[k]] & 127u; run_end = rs[k + 1]; } else run_end = 0xffffffffu;
-    };
-    // The segment is walked in aligned 16-byte groups whatever runs it holds (a cold context's run is
-    // a few bins: walking run by run would mean byte loads and stores for most of such a segment).
-    auto group16 = [&](U4 &v, uint32_t at) {
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        if (at + 16 <= run_end && at + 16 <= to) {               // no run ends inside
-#pragma unroll
-            for (int j = 0; j < 16; j += 2) {
-                const uint32_t sh = (j & 3) * 8, d = w[j >> 2] >> sh, b0 = d & 1u, b1 = (d >> 8) & 1u;
-                const uint2 e = pair[st];
-                const uint32_t mid = (e.x >> (8 * b0)) & 0xffu;
-                const uint32_t c0 = code_context(st, b0), c1 = code_context(mid, b1);
-                st = (e.y >> (8 * (2 * b0 + b1))) & 0xffu;
-                w[j >> 2] = (w[j >> 2] & ~(0xffffu << sh)) | ((c0 | c1 << 8) << sh);
-            }
-        } else {
-            for (uint32_t j = 0; j < 16 && at + j < to; j++) {
-                if (at + j == run_end) next_run();
-                const uint32_t sh = (j & 3) * 8, bin = (w[j >> 2] >> sh) & 1u;
-                const uint32_t code = code_context(st, bin);
-                st = chain_next(next, st, bin);
-                w[j >> 2] = (w[j >> 2] & ~(0xffu << sh)) | (code << sh);
-            }
-        }
-        v = U4{w[0], w[1], w[2], w[3]};
-    };
-    uint32_t at = from;                                          // a multiple of kChunk; `sorted` is padded past rs[nk]
-    if (at + 64 <= to) {                                         // a whole cache line per lane per trip, the next one in flight
-        U4 *q = reinterpret_cast<U4 *>(so + at);
-        U4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
-        for (; at + 64 <= to; at += 64) {
-            q = reinterpret_cast<U4 *>(so + at);
+    uint32_t *my_cnt = cnt + lane;                               // counters of contexts 2j, 2j+1 at my_cnt[64 j]
+    uint32_t *my_bits = bits + lane;                             // dword j at my_bits[64 j]
+    uint8_t *cnt_b = reinterpret_cast<uint8_t *>(my_cnt), *bits_b = reinterpret_cast<uint8_t *>(my_bits);
+    // Visit the chunk's 16-byte groups (8 records; a slice's records are padded with no-ops to a whole group), a
+    // cache line of records per trip with the next one in flight (see for_codes_all).
+    auto for_groups = [&](auto &&f) {
+        uint32_t i = i0;
+        U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+        if (i + 32 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i); v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
+        for (; i + 32 <= i1; i += 32) {
             U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-            if (at + 128 <= to) { n0 = q[4]; n1 = q[5]; n2 = q[6]; n3 = q[7]; }
-            group16(v0, at); group16(v1, at + 16); group16(v2, at + 32); group16(v3, at + 48);
-            q[0] = v0; q[1] = v1; q[2] = v2; q[3] = v3;
+            if (i + 64 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i + 32); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+            f(v0); f(v1); f(v2); f(v3);
             v0 = n0; v1 = n1; v2 = n2; v3 = n3;
         }
+        for (; i < i1; i += 8) f(*reinterpret_cast<const U4 *>(r + i));
+    };
+    for_groups([&](const U4 &v) {                                // pass 1
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t e[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) e[j] = sel_tab[((w[j >> 1] >> ((j & 1) * 16)) >> 1) & 0x7ffu];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)                         // 1 << e: the shift takes the low five bits, 0 or 16
+            __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(cnt_b + (e[j] & ~255u)), 1u << (e[j] & 31u), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    });
+    {
+        uint32_t run = 0;                                        // exclusive prefix; the spare row starts at 1024
+        for (uint32_t j = 0; j < cnt_rows; j++) {
+            const uint32_t c = my_cnt[64 * j], c0 = c & 0xffffu, c1 = c >> 16;
+            const uint32_t s0 = 2 * j < nk ? run : 1024u, s1 = 2 * j + 1 < nk ? run + c0 : 1024u;
+            my_cnt[64 * j] = s0 | s1 << 16;
+            run += (2 * j < nk ? c0 : 0u) + (2 * j + 1 < nk ? c1 : 0u);
+        }
     }
-    for (; at < to; at += 16) {
-        U4 *q = reinterpret_cast<U4 *>(so + at);
-        U4 v = q[0];
-        group16(v, at);
-        q[0] = v;
+    for_groups([&](const U4 &v) {                                // pass 2
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t e[8], pos[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) e[j] = sel_tab[((w[j >> 1] >> ((j & 1) * 16)) >> 1) & 0x7ffu];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)
+            pos[j] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(cnt_b + (e[j] & ~255u)), 1u << (e[j] & 31u), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t at = (pos[j] >> (e[j] & 31u)) & 2047u;            // < 1024: a context bin's place; the spare row counts from 1024
+            const uint32_t row = at >> 5 < 32u ? at >> 5 : 32u;
+            const uint32_t bin = (w[j >> 1] >> ((j & 1) * 16)) & 1u;
+            __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(bits_b + row * 256u), bin << (at & 31u), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    });
+    // out, transposed: flat element f of the wave's 64 rows <-> (chunk f / row, column f % row)
+    {
+        uint32_t *dst = lbits + size_t(gc0) * 32;
+        const uint32_t lim = gc0 < total_chunks ? (total_chunks - gc0 < 64 ? total_chunks - gc0 : 64) * 32 : 0;
+        for (uint32_t f = lane; f < lim; f += 64) dst[f] = bits[64 * (f & 31u) + (f >> 5)];
     }
-    if (to == run_end) next_run();                               // the run (and any empty ones after it) ends with the segment
+    if (nk) {
+        uint16_t *dst = lend + size_t(gc0) * nk;
+        const uint32_t lim = gc0 < total_chunks ? (total_chunks - gc0 < 64 ? total_chunks - gc0 : 64) * nk : 0;
+        uint32_t ch = lane / nk, k = lane - ch * nk;
+        const uint32_t dch = 64 / nk, dk = 64 - dch * nk;
+        for (uint32_t f = lane; f < lim; f += 64) {
+            dst[f] = uint16_t(cnt[64 * (k >> 1) + ch] >> (16 * (k & 1u)));
+            ch += dch; k += dk;
+            if (k >= nk) { k -= nk; ch++; }
+        }
+    }
 }
 
-// A5: one lane per chunk (a quarter of a sort block), its records in stream order.  After the chains
-// the resolved code at sorted position qoff[chunk][k] holds the state of context k when the chunk is
-// entered, so a lane loads those states (one byte per context, in LDS, laid out (k, lane) like
+// One lane per (slice, context), a wave = kChainLanes consecutive contexts of one slice: the state chain of the
+// context through the slice (cabac_code.h:43-47), chunk by chunk.  At chunk c the lane notes the state
+// (est[gc][k]: what k_k1p_replay starts chunk c from), then walks the context's bins of the chunk -- bits
+// [end[k-1], end[k]) of the chunk's bit string -- up to eight per look-up (k_k1p_tn's table, in LDS).  The loads
+// are one row of `lend` and pieces of one 128-byte bit string per chunk; they do not depend on the state and
+// run ahead of the chain: end positions four chunks ahead, the 64-bit window a run starts in two ahead.
+// They are unconditional (the arrays are padded past the last chunk, and in front for k = 0): a load inside a
+// branch is waited for at the end of the branch, which would put its whole latency into every step.
+//
+// The chain is a sequence of dependent look-ups and loads, chunk after chunk: what hides its latency is other
+// waves, and a batch has only slices x contexts lanes to give (44 000 for 512 slices of a 1080p clip).  So a
+// wave takes only kChainLanes of them -- the other lanes stay idle -- which also bounds a step by the longest
+// of kChainLanes runs instead of the longest of 64.
+constexpr uint32_t kChainLanes = 16, kChainWaves = 8;
+__global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint32_t n_slices, uint32_t groups, const int32_t *status,
+                                                      const uint8_t *tng, const uint32_t *lbits, const uint16_t *lend,
+                                                      const uint8_t *init_states, uint8_t *est, uint8_t *final_states) {
+    __shared__ uint8_t tn[kTnBytes];
+    for (uint32_t i = threadIdx.x; i < kTnBytes / 16; i += 64 * kChainWaves) reinterpret_cast<uint4 *>(tn)[i] = reinterpret_cast<const uint4 *>(tng)[i];
+    __syncthreads();
+    const uint32_t wave = blockIdx.x * kChainWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t s = wave / groups, k = (wave - s * groups) * kChainLanes + lane, nk = p.n_states;
+    if (lane >= kChainLanes || s >= n_slices || status[s] != AVR_SLICE_OK || k >= nk) return;
+    const uint32_t col = p.index[k], row4 = ((nk + 3) >> 2) << 2;
+    uint32_t st = init_states[size_t(s) * p.ns_full + col] & 127u;
+    const uint32_t c0 = p.chunk_base[s], nc = (p.n_bins[s] + kChunk - 1) / kChunk;
+    const uint16_t *le = lend + size_t(c0) * nk + k;             // end[k] of the chunk being requested (four ahead)
+    const uint32_t *bw_ahead = lbits + size_t(c0) * 32;          // bit string of the chunk whose window is being requested (two ahead)
+    const uint32_t *bw_cur = bw_ahead;                           // bit string of the chunk being walked
+    uint8_t *eo = est + size_t(c0) * row4 + k;
+    auto ends = [&]() {                                          // (end[k-1], end[k]), then on to the next chunk
+        const uint32_t e1 = le[0], em = le[-1];
+        le += nk;
+        return make_uint2(k ? em : 0u, e1);
+    };
+    auto window = [&](const uint32_t *bw, uint32_t pos) {        // bits 32 (pos / 32) .. + 63 of a chunk's string
+        const uint32_t wi = (pos >> 5) & 31u;
+        return make_uint2(bw[wi], bw[wi < 31u ? wi + 1 : 31u]);
+    };
+    uint2 e0 = ends(), e1 = ends(), e2 = ends(), e3 = ends();
+    uint2 w0 = window(bw_ahead, e0.x), w1 = window(bw_ahead + 32, e1.x);
+    bw_ahead += 64;
+#pragma unroll 4
+    for (uint32_t c = 0; c < nc; c++) {
+        const uint2 e4 = ends();
+        const uint2 w2 = window(bw_ahead, e2.x);
+        bw_ahead += 32;
+        *eo = uint8_t(st);
+        eo += row4;
+        uint32_t pos = e0.x;
+        const uint32_t end = e0.y;
+        if (pos < end && st < 126) {                             // pStateIdx 63 never moves
+            uint2 win = w0;
+            for (;;) {                                           // up to 32 bins per window
+                uint32_t avail = __builtin_amdgcn_alignbit(win.y, win.x, pos & 31u);
+                uint32_t left = end - pos < 32u ? end - pos : 32u;
+                pos += left;
+                do {
+                    const uint32_t n = left < 8u ? left : 8u;
+                    st = tn[(128u << n) - 128u + ((st << n) | (avail & ((1u << n) - 1u)))];
+                    avail >>= 8;
+                    left -= n;
+                } while (left);
+                if (pos >= end) break;
+                win = window(bw_cur, pos);
+            }
+        }
+        bw_cur += 32;
+        e0 = e1; e1 = e2; e2 = e3; e3 = e4;
+        w0 = w1; w1 = w2;
+    }
+    if (final_states) final_states[size_t(s) * p.ns_full + col] = uint8_t(st);
+}
+
+// Replay: one lane per chunk, its records in stream order.  est[gc][k] is the state of context k when the
+// chunk is entered, so a lane loads those states (one byte per context, in LDS, laid out (k, lane) like
 // k_cabac_encode's) and simply plays the chunk's bins: state before the bin -> resolved code,
 // cabac_code.h:43-47 -> next state.  Everything it touches in HBM is read or written once, in order:
-// records in, codes out.  (The form this replaced fetched every bin's code back from the sorted
-// order through a 32-bit position the scatter kernel had stored per bin: 8 more bytes of traffic per
-// bin and a gather of 64 cache lines per load; 0.97 ms on config 2.)
+// records in, codes out.
 //
 // The step is branch-free.  Bypass, terminate and padding records go through pseudo contexts nk+1..
 // whose pseudo states 128.. never move, and one LDS table gives, per state, both successors and
 // both resolved codes:  T[st] = next if MPS | next if LPS << 8 | code(bin 0) << 16 | code(bin 1) << 24.
 constexpr uint32_t kStBypass = 128, kStTerminate = 129, kStPad = 130, kStNone = 131, kReplayTable = 192;
-
-// The entry states of every chunk, four contexts per thread: est[chunk][k] = state of context k at the
-// chunk's first bin, read off the resolved code at the sorted position where the chunk's bins of k
-// start (a context without a bin from there on gets whatever lies at the end of its run: it is never
-// looked at).  Done apart from the replay so that a replay lane starts from independent loads.
-__global__ __launch_bounds__(256) void k_k1p_entry(Plan p, uint32_t total_chunks, const int32_t *status, const uint32_t *qoff,
-                                                  const uint8_t *sorted, const uint8_t *init_states, uint32_t *est,
-                                                  uint32_t chunks_per_block, uint32_t recip) {
-    // Consecutive threads take consecutive context groups of one chunk: the chunk's offsets are read and
-    // its states written as one contiguous row.  (Measured: chunk-minor threads with est[kw][chunk], which
-    // would make the sorted-order reads neighbours instead, is 3x slower: the offset reads become strided.)
-    // A workgroup takes chunks_per_block = 256 / nkw whole rows; thread -> (row, group) by a multiply with
-    // recip = ceil(2^16 / nkw), exact for thread ids below 256.
-    const uint32_t nk = p.n_states, nkw = (nk + 3) >> 2;
-    const uint32_t row = (threadIdx.x * recip) >> 16, kw = threadIdx.x - row * nkw, k0 = kw * 4;
-    const uint32_t gc = blockIdx.x * chunks_per_block + row;
-    if (row >= chunks_per_block || gc >= total_chunks) return;
-    const uint32_t s = p.chunk_slice[gc];
-    if (status[s] != AVR_SLICE_OK) return;
-    const uint32_t c = gc - p.chunk_base[s];
-    if (c * kChunk >= p.n_bins[s]) return;
-    const uint8_t *so = sorted + p.res_off[s];
-    const uint32_t *bo = qoff + (size_t(p.blk_base[s]) * 4 + c) * nk;    // chunk c is quarter c & 3 of sort block c >> 2
-    const uint8_t *init = init_states + size_t(s) * p.ns_full;
-    uint32_t word = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t k = k0 + j < nk ? k0 + j : nk - 1;
-        const uint32_t cd = so[bo[k]];
-        word |= (cd < 252 ? cd >> 1 : init[p.index[k]] & 127u) << (8 * j);  // pStateIdx 63 never moves
-    }
-    est[size_t(gc) * nkw + kw] = word;
-}
 
 __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *est, uint8_t *res,
                                                     const int32_t *status) {
@@ -964,25 +754,21 @@ inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 }
 
 // Phase A: records + initial states -> resolved codes `res` (slice i at res + res_off[i]).
-// `w` is workspace for the sort (sorted bins, histograms, run starts, segments), laid out for the
-// caller's context count; the kernels index it by the dense count, which is known after the histogram
-// pass (the one host round trip of the path: four bytes, to size the later launches).
+// `w` is workspace (per-chunk bit strings, end positions and entry states, tables), laid out for the
+// caller's context count; the kernels index it by the dense count, which is known after the census
+// (the one host round trip of the path: four bytes, to size the later launches).
 struct ResolveLayout {
-    uint64_t sorted, hist16, boff, run_start, seg, entry, qoff, est, meta, total;
+    uint64_t lbits, lend, est, meta, total;
 };
 static inline ResolveLayout resolve_layout(size_t n_slices, uint32_t ns, const avr_chunk_plan *pl) {
     ResolveLayout L;
     uint64_t at = 0;
     auto take = [&](uint64_t bytes) { const uint64_t o = at; at += up256(bytes); return o; };
-    L.sorted = take(pl->res_total + 32);
-    L.hist16 = take(uint64_t(pl->total_blocks) * ns * 2 + 16);
-    L.boff = take(uint64_t(pl->total_blocks) * ns * 4 + 16);
-    L.run_start = take(n_slices * uint64_t(ns + 1) * 4 + 16);
-    L.seg = take(uint64_t(pl->total_chunks) * sizeof(Seg));
-    L.entry = take(uint64_t(pl->total_chunks) + 16);
-    L.qoff = take(uint64_t(pl->total_blocks) * ns * 16 + 16);
+    (void)n_slices;
+    L.lbits = take(uint64_t(pl->total_chunks + 64) * 128);       // + 64 chunks: the chains read a few chunks ahead, unconditionally
+    L.lend = take(uint64_t(pl->total_chunks + 64) * ns * 2 + 256) + 128;     // a pad in front: k_k1p_ctxchain reads lend[-1]
     L.est = take(uint64_t(pl->total_chunks) * ((ns + 3) / 4) * 4 + 16);
-    L.meta = take(256 + 2048 + 2048);                            // used[32] + n_dense, table[1024], index[1024]
+    L.meta = take(256 + 2048 + 2048 + kTnBytes);                 // used[32] + n_dense, table[1024], index[1024], tn
     L.total = at;
     return L;
 }
@@ -991,49 +777,42 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
                                  const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, int32_t *status, uint8_t *final_states) {
     const uint32_t ns = p.ns_full;
     const ResolveLayout L = resolve_layout(n_slices, ns, pl);
-    uint8_t *sorted = w + L.sorted;
-    uint16_t *hist16 = reinterpret_cast<uint16_t *>(w + L.hist16);
-    uint32_t *boff = reinterpret_cast<uint32_t *>(w + L.boff);
-    uint32_t *run_start = reinterpret_cast<uint32_t *>(w + L.run_start);
-    Seg *seg = reinterpret_cast<Seg *>(w + L.seg);
-    uint8_t *entry = w + L.entry;
-    uint32_t *qoff = reinterpret_cast<uint32_t *>(w + L.qoff);
-    uint32_t *est = reinterpret_cast<uint32_t *>(w + L.est);
+    uint32_t *lbits = reinterpret_cast<uint32_t *>(w + L.lbits);
+    uint16_t *lend = reinterpret_cast<uint16_t *>(w + L.lend);
+    uint8_t *est = w + L.est;
     uint32_t *used = reinterpret_cast<uint32_t *>(w + L.meta);   // [32], then n_dense
     uint32_t *n_dense = used + 32;
     uint16_t *table = reinterpret_cast<uint16_t *>(w + L.meta + 256), *index = table + 1024;
+    uint8_t *tn = w + L.meta + 256 + 4096;
     p.table = table;
     p.index = index;
     hipError_t e;
     if ((e = hipMemsetAsync(used, 0, 256, s)) != hipSuccess) return e;
     if (final_states && ns && (e = hipMemcpyAsync(final_states, init_states, size_t(n_slices) * ns, hipMemcpyDeviceToDevice, s)) != hipSuccess)
         return e;                                                // contexts without bins keep their state
-    hipLaunchKernelGGL(k_k1p_hist, dim3(pl->total_blocks), dim3(256), 0, s, p, status, hist16, used);
+    hipLaunchKernelGGL(k_k1p_census, dim3(pl->total_blocks), dim3(256), 0, s, p, status, used);
     hipLaunchKernelGGL(k_k1p_densemap, dim3(1), dim3(1024), 0, s, used, table, index, n_dense);
+    hipLaunchKernelGGL(k_k1p_tn, dim3((kTnBytes + 255) / 256), dim3(256), 0, s, tn);
     uint32_t n_states = 0;
     if ((e = hipMemcpyAsync(&n_states, n_dense, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     p.n_states = n_states;
-    uint32_t key_bits = 0;
-    while ((1u << key_bits) < n_states) key_bits++;
-    const uint32_t chunk_blocks = (pl->total_chunks + 255) / 256;
+    {
+        // the waves of a workgroup share the renumbering table; each has its own counters and bit strings
+        const uint32_t per_wave = (33 + (n_states + 2) / 2) * 64 * 4;
+        const uint32_t waves = per_wave * 4 <= 60 * 1024 ? 4 : per_wave * 2 <= 60 * 1024 ? 2 : 1;
+        const uint32_t lds = waves * per_wave;
+        if (lds > 60 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_k1p_local), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(k_k1p_local, dim3((pl->total_chunks + 64 * waves - 1) / (64 * waves)), dim3(64 * waves), lds, s, p,
+                           pl->total_chunks, status, lbits, lend);
+    }
     if (n_states > 0) {
-        hipLaunchKernelGGL(k_k1p_scan, dim3(n_slices), dim3(1024), 0, s, p, hist16, boff, run_start);
-        const uint32_t scatter_lds = 20 * ((n_states + 63) & ~63u) + 3 * kSortBlock;
-        auto scatter = key_bits <= 1 ? k_k1p_scatter<1> : key_bits == 2 ? k_k1p_scatter<2> : key_bits == 3 ? k_k1p_scatter<3> :
-                       key_bits == 4 ? k_k1p_scatter<4> : key_bits == 5 ? k_k1p_scatter<5> : key_bits == 6 ? k_k1p_scatter<6> :
-                       key_bits == 7 ? k_k1p_scatter<7> : key_bits == 8 ? k_k1p_scatter<8> : key_bits == 9 ? k_k1p_scatter<9> :
-                                                                                               k_k1p_scatter<10>;
-        hipLaunchKernelGGL(scatter, dim3(pl->total_blocks), dim3(256), scatter_lds, s, p, status, boff, run_start, sorted, qoff);
-        hipLaunchKernelGGL(k_k1p_spec, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
-                           sorted, seg);
-        hipLaunchKernelGGL(k_k1p_link, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
-                           sorted, seg, entry);
-        hipLaunchKernelGGL(k_k1p_chain, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, status, run_start, init_states,
-                           sorted, seg, entry, final_states);
-        const uint32_t nkw = (n_states + 3) / 4, cpb = 256 / nkw;           // nkw <= 256
-        hipLaunchKernelGGL(k_k1p_entry, dim3((pl->total_chunks + cpb - 1) / cpb), dim3(256), 0, s, p, pl->total_chunks, status, qoff,
-                           sorted, init_states, est, cpb, (65536 + nkw - 1) / nkw);
+        const uint32_t groups = (n_states + kChainLanes - 1) / kChainLanes;
+        hipLaunchKernelGGL(k_k1p_ctxchain, dim3((n_slices * groups + kChainWaves - 1) / kChainWaves), dim3(64 * kChainWaves), 0, s, p,
+                           n_slices, groups, status, tn, lbits, lend, init_states, est, final_states);
     }
     // the waves of a workgroup share the two tables; each has its own state rows: as many waves as 60 KiB hold (1 .. 4)
     const uint32_t per_wave = ((n_states + 8) / 4) * 256;
@@ -1044,7 +823,7 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_k1p_replay, dim3((pl->total_chunks + 64 * replay_waves - 1) / (64 * replay_waves)), dim3(64 * replay_waves),
-                       replay_lds, s, p, pl->total_chunks, est, res, status);
+                       replay_lds, s, p, pl->total_chunks, reinterpret_cast<const uint32_t *>(est), res, status);
     return hipGetLastError();
 }
 
