@@ -306,7 +306,9 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
     for (uint32_t i = threadIdx.x; i < kTnBytes / 16; i += 64 * kChainWaves) reinterpret_cast<uint4 *>(tn)[i] = reinterpret_cast<const uint4 *>(tng)[i];
     __syncthreads();
     const uint32_t wave = blockIdx.x * kChainWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint32_t s = wave / groups, k = (wave - s * groups) * kChainLanes + lane, nk = p.n_states;
+    // group g of a slice takes contexts g, g + groups, g + 2 groups ...: neighbouring contexts (the hot ones of a
+    // stream sit next to each other: the coefficient contexts of one block category) go to different waves
+    const uint32_t s = wave / groups, k = (wave - s * groups) + lane * groups, nk = p.n_states;
     if (lane >= kChainLanes || s >= n_slices || status[s] != AVR_SLICE_OK || k >= nk) return;
     const uint32_t col = p.index[k], row4 = ((nk + 3) >> 2) << 2;
     uint32_t st = init_states[size_t(s) * p.ns_full + col] & 127u;
@@ -320,26 +322,24 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
         le += nk;
         return make_uint2(k ? em : 0u, e1);
     };
-    auto window = [&](const uint32_t *bw, uint32_t pos) {        // bits 32 (pos / 32) .. + 63 of a chunk's string
-        const uint32_t wi = (pos >> 5) & 31u;
-        return make_uint2(bw[wi], bw[wi < 31u ? wi + 1 : 31u]);
+    auto window = [&](const uint32_t *bw, uint32_t pos) {        // bits 32 (pos / 32) .. + 127 of a chunk's string
+        const uint32_t wi = (pos >> 5) & 31u;                    // (past dword 31: the next chunk's, never used -- a run ends by bit 1024)
+        return make_uint4(bw[wi], bw[wi + 1], bw[wi + 2], bw[wi + 3]);
     };
     uint2 e0 = ends(), e1 = ends(), e2 = ends(), e3 = ends();
-    uint2 w0 = window(bw_ahead, e0.x), w1 = window(bw_ahead + 32, e1.x);
+    uint4 w0 = window(bw_ahead, e0.x), w1 = window(bw_ahead + 32, e1.x);
     bw_ahead += 64;
 #pragma unroll 4
     for (uint32_t c = 0; c < nc; c++) {
         const uint2 e4 = ends();
-        const uint2 w2 = window(bw_ahead, e2.x);
+        const uint4 w2 = window(bw_ahead, e2.x);
         bw_ahead += 32;
         *eo = uint8_t(st);
         eo += row4;
         uint32_t pos = e0.x;
         const uint32_t end = e0.y;
         if (pos < end && st < 126) {                             // pStateIdx 63 never moves
-            uint2 win = w0;
-            for (;;) {                                           // up to 32 bins per window
-                uint32_t avail = __builtin_amdgcn_alignbit(win.y, win.x, pos & 31u);
+            auto walk32 = [&](uint32_t avail) {                  // up to 32 bins from `pos`
                 uint32_t left = end - pos < 32u ? end - pos : 32u;
                 pos += left;
                 do {
@@ -348,9 +348,15 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
                     avail >>= 8;
                     left -= n;
                 } while (left);
-                if (pos >= end) break;
-                win = window(bw_cur, pos);
-            }
+            };
+            auto walk = [&](const uint4 &win) {                  // up to 96 bins from `pos`, out of a 128-bit window
+                const uint32_t sh = pos & 31u;
+                walk32(__builtin_amdgcn_alignbit(win.y, win.x, sh));
+                if (pos < end) walk32(__builtin_amdgcn_alignbit(win.z, win.y, sh));
+                if (pos < end) walk32(__builtin_amdgcn_alignbit(win.w, win.z, sh));
+            };
+            walk(w0);                                            // the window requested two chunks ago
+            while (pos < end) walk(window(bw_cur, pos));         // a run of more than 96 bins: fetch as it goes
         }
         bw_cur += 32;
         e0 = e1; e1 = e2; e2 = e3; e3 = e4;
