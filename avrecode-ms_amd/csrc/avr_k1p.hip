@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks
 // waves, and a batch has only slices x contexts lanes to give (44 000 for 512 slices of a 1080p clip).  So a
 // wave takes only kChainLanes of them -- the other lanes stay idle -- which also bounds a step by the longest
 // of kChainLanes runs instead of the longest of 64.
-constexpr uint32_t kChainLanes = 16, kChainWaves = 8;
-__global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint32_t n_slices, uint32_t groups, const int32_t *status,
+constexpr uint32_t kChainLanes = 22, kChainWaves = 8;         // kChainLanes: the fewest lanes a wave takes
+__global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint32_t n_slices, uint32_t groups, uint32_t chain_lanes, const int32_t *status,
                                                       const uint8_t *tng, const uint32_t *lbits, const uint16_t *lend,
                                                       const uint8_t *init_states, uint8_t *est, uint8_t *final_states) {
     __shared__ uint8_t tn[kTnBytes];
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
     // group g of a slice takes contexts g, g + groups, g + 2 groups ...: neighbouring contexts (the hot ones of a
     // stream sit next to each other: the coefficient contexts of one block category) go to different waves
     const uint32_t s = wave / groups, k = (wave - s * groups) + lane * groups, nk = p.n_states;
-    if (lane >= kChainLanes || s >= n_slices || status[s] != AVR_SLICE_OK || k >= nk) return;
+    if (lane >= chain_lanes || s >= n_slices || status[s] != AVR_SLICE_OK || k >= nk) return;
     const uint32_t col = p.index[k], row4 = ((nk + 3) >> 2) << 2;
     uint32_t st = init_states[size_t(s) * p.ns_full + col] & 127u;
     const uint32_t c0 = p.chunk_base[s], nc = (p.n_bins[s] + kChunk - 1) / kChunk;
@@ -365,44 +365,64 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
     if (final_states) final_states[size_t(s) * p.ns_full + col] = uint8_t(st);
 }
 
-// Replay: one lane per chunk, its records in stream order.  est[gc][k] is the state of context k when the
-// chunk is entered, so a lane loads those states (one byte per context, in LDS, laid out (k, lane) like
-// k_cabac_encode's) and simply plays the chunk's bins: state before the bin -> resolved code,
-// cabac_code.h:43-47 -> next state.  Everything it touches in HBM is read or written once, in order:
-// records in, codes out.
+__device__ __forceinline__ CodeEntry device_code_entry(uint32_t c);
+
+// Replay + phase B1: one lane per chunk, its records in stream order.  est[gc][k] is the state of context k
+// when the chunk is entered, so a lane loads those states (one byte per context, in LDS, laid out (k, lane)
+// like k_cabac_encode's) and simply plays the chunk's bins: state before the bin -> resolved code,
+// cabac_code.h:43-47 -> next state.  Records in, codes out, each read or written once, in order.
 //
-// The step is branch-free.  Bypass, terminate and padding records go through pseudo contexts nk+1..
-// whose pseudo states 128.. never move, and one LDS table gives, per state, both successors and
-// both resolved codes:  T[st] = next if MPS | next if LPS << 8 | code(bin 0) << 16 | code(bin 1) << 24.
-constexpr uint32_t kStBypass = 128, kStTerminate = 129, kStPad = 130, kStNone = 131, kReplayTable = 192;
+// The same walk yields the chunk's stretch summary (b1_stretch of avr_k1p.h, which k_k1p_b1 runs over
+// finished codes when a caller brings its own): with the state in hand, the bin's LPS ranges are one more
+// field of the same table entry, so phase B1 costs its arithmetic and no pass of its own.  A stretch runs to
+// the first coded LPS at or past the chunk's end: the lane keeps playing the next chunk's records for that (its
+// private state table stays exact), without writing their codes -- those belong to the next chunk's lane.
+//
+// The step is branch-free up to B1's modes.  Two look-ups per bin: sel_off[selector] = where the bin's state
+// byte lives in the lane's column (bypass, terminate, padding and anything that is no context of the batch go
+// to pseudo contexts whose pseudo states 128.. never move), and info[state << 1 | bin] = { LPS ranges of the
+// state's four range quarters, next state | resolved code << 8 | B1's meta << 16 }.
+constexpr uint32_t kStBypass = 128, kStTerminate = 129, kStPad = 130, kStNone = 131, kReplayStates = 132;
 
 __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *est, uint8_t *res,
-                                                    const int32_t *status) {
-    extern __shared__ uint32_t replay_lds[];                     // T[kReplayTable], then per wave: state dwords [(nk+8)/4][64]
-    __shared__ uint16_t tab[1024];                               // caller's context number -> dense id
-    uint32_t *T = replay_lds;
+                                                    const int32_t *status, Stretch *stretch, uint32_t max_stretch) {
+    extern __shared__ uint32_t replay_lds[];                     // per wave: state dwords [(nk+8)/4][64]
+    __shared__ uint2 info[2 * kReplayStates];
+    __shared__ uint32_t sel_off[2048];
     const uint32_t lane = threadIdx.x & 63, nk = p.n_states;
-    uint8_t *stb = reinterpret_cast<uint8_t *>(replay_lds + kReplayTable) + (threadIdx.x >> 6) * (((nk + 8) >> 2) << 8) + lane * 4;
-    for (uint32_t k = threadIdx.x; k < 1024; k += blockDim.x) tab[k] = p.table[k];
-    for (uint32_t st = threadIdx.x; st < kReplayTable; st += blockDim.x) {
-        uint32_t e;
-        if (st < 128) e = d_tables.packed[st][1] | code_context(st, 0) << 16 | code_context(st, 1) << 24;
-        else {
-            const uint32_t c0 = st == kStBypass ? kCodeBypass : st == kStTerminate ? code_terminate(0) : kCodePad;
-            const uint32_t c1 = st == kStBypass ? kCodeBypass | 1 : st == kStTerminate ? code_terminate(1) : kCodePad;
-            e = st | st << 8 | c0 << 16 | c1 << 24;
+    uint8_t *stb = reinterpret_cast<uint8_t *>(replay_lds) + (threadIdx.x >> 6) * (((nk + 8) >> 2) << 8) + lane * 4;
+    for (uint32_t sel = threadIdx.x; sel < 2048; sel += blockDim.x) {
+        // contexts get their dense id; 1024 (bypass), 1025 (terminate), 1026 (no-op) -> nk+1, nk+2, nk+3; the rest nk / nk+4
+        const uint32_t over = (sel < 1023u ? 1023u : sel > 1027u ? 1027u : sel) - 1023u;
+        const uint32_t dense = sel < 1024u ? uint32_t(p.table[sel]) : kNotUsed;
+        const uint32_t kk = (dense < nk ? dense : nk) + over;
+        sel_off[sel] = ((kk & ~3u) << 6) + (kk & 3u);
+    }
+    for (uint32_t i = threadIdx.x; i < 2 * kReplayStates; i += blockDim.x) {
+        const uint32_t st = i >> 1, bin = i & 1u;
+        uint32_t next, code;
+        if (st < 128) {
+            const uint32_t nx = d_tables.packed[st][1];
+            next = ((bin ^ st) & 1u) ? (nx >> 8) & 0xffu : nx & 0xffu;
+            code = code_context(st, bin);
+        } else {
+            next = st;
+            code = st == kStBypass ? kCodeBypass | bin : st == kStTerminate ? code_terminate(bin) : kCodePad;
         }
-        T[st] = e;
+        const CodeEntry ce = device_code_entry(code);
+        info[i] = make_uint2(ce.row, next | code << 8 | ce.meta << 16);
     }
     __syncthreads();
     const uint32_t gc = blockIdx.x * blockDim.x + threadIdx.x;
     if (gc >= total_chunks) return;
     const uint32_t s = p.chunk_slice[gc];
-    if (status[s] != AVR_SLICE_OK) return;
+    Stretch o;
+    o.first = kNone; o.end = 0; o.exit_q = 0; o.too_long = 0; o.pad[0] = o.pad[1] = 0;
+    for (int q = 0; q < 4; q++) { o.t_exit[q] = 0; o.r_exit[q] = 0; }
+    if (status[s] != AVR_SLICE_OK) { stretch[gc] = o; return; }
     const uint32_t c = gc - p.chunk_base[s];
     const uint32_t n = p.n_bins[s], i0 = c * kChunk;
-    const uint32_t i1 = i0 + kChunk < n ? i0 + kChunk : n;
-    if (i0 >= n) return;
+    const uint32_t i1 = i0 + kChunk < n ? i0 + kChunk : n;      // end of the chunk's own bins = where a closing LPS may come from
     {
         const uint32_t nkw = (nk + 3) >> 2;
         const uint32_t *e = est + size_t(gc) * nkw;
@@ -413,53 +433,113 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
     }
     const uint16_t *r = p.recs + p.rec_off[s];
     uint8_t *ro = res + p.res_off[s];
-    // 8 records (16 bytes) -> 8 codes
-    auto eight = [&](const U4 &v, uint32_t &c0, uint32_t &c1) {
+    // ---- B1 (the logic of b1_stretch): 0 = looking for the LPS that opens the stretch, 1 = four candidate ranges,
+    // 2 = they have merged, 3 = closed
+    const uint32_t limit = i0 + kChunk;
+    uint32_t mode = 0, R[4] = {510, 510, 510, 510}, T[4] = {0, 0, 0, 0}, Rm = 510, Tm = 0, end = 0;
+    bool merged = false;
+    if (c == 0) { o.first = 0; mode = 2; merged = true; }        // opens at bin 0 with the initial range 510 (cabac_code.h:30)
+    auto one = [&](uint32_t idx, const uint2 &e) {               // bin idx (< n) with table entry e, any mode
+        const CodeEntry ce{e.x, e.y >> 16};
+        const bool boundary = ce.meta & 1u;                      // a coded LPS (code_is_boundary)
+        if (mode == 0) {
+            if (idx < i1 && boundary) {
+                o.first = idx;
+                for (uint32_t q = 0; q < 4; q++) { uint32_t sh; R[q] = post_lps_range(ce.row, q, &sh); }
+                mode = 1;
+            }
+        } else if (mode == 1) {
+            const bool closing = idx >= limit && boundary;
+            if (closing)
+                for (uint32_t q = 0; q < 4; q++) o.exit_q |= uint8_t(((R[q] >> 6) & 3) << (2 * q));
+            for (uint32_t q = 0; q < 4; q++) T[q] += step_range(ce, &R[q]);
+            if (closing) { end = idx + 1; mode = 3; }
+            else if (R[0] == R[1] && R[1] == R[2] && R[2] == R[3]) { Rm = R[0]; mode = 2; merged = true; }
+        } else if (mode == 2) {
+            const bool closing = idx >= limit && boundary;
+            if (closing) o.exit_q = uint8_t(((Rm >> 6) & 3) * 0x55u);
+            Tm += step_range(ce, &Rm);
+            if (closing) { end = idx + 1; mode = 3; }
+            else if (idx >= limit && idx - i0 > max_stretch) { o.too_long = 1; end = idx + 1; mode = 3; }
+        }
+    };
+    // 8 records (16 bytes) -> 8 codes; e[] = their table entries
+    auto eight = [&](const U4 &v, uint32_t &c0, uint32_t &c1, uint2 e[8]) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t off[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) off[j] = sel_off[((w[j >> 1] >> ((j & 1) * 16)) >> 1) & 0x7ffu];
         uint32_t cc[2] = {0, 0};
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++) {
-            const uint32_t rec = w[j >> 1] >> ((j & 1) * 16);
-            const uint32_t sel = (rec >> 1) & 0x7ffu, bin = rec & 1;
-            // contexts get their dense id; 1024 (bypass), 1025 (terminate), 1026 (no-op) -> nk+1, nk+2, nk+3
-            const uint32_t over = (sel < 1023u ? 1023u : sel > 1027u ? 1027u : sel) - 1023u;
-            const uint32_t dense = tab[sel & 1023u];
-            const uint32_t kk = (sel < 1024u && dense < nk ? dense : nk) + over;
-            uint8_t *sp = stb + ((kk & ~3u) << 6) + (kk & 3);
+            const uint32_t bin = (w[j >> 1] >> ((j & 1) * 16)) & 1u;
+            uint8_t *sp = stb + off[j];
             const uint32_t st = *sp;
-            const uint32_t e = T[st];
-            *sp = uint8_t(e >> (8 * ((bin ^ st) & 1)));
-            cc[j >> 2] |= ((e >> (16 + 8 * bin)) & 0xffu) << (8 * (j & 3));
+            e[j] = info[(st << 1) | bin];
+            *sp = uint8_t(e[j].y);
+            cc[j >> 2] |= ((e[j].y >> 8) & 0xffu) << (8 * (j & 3));
         }
         c0 = cc[0]; c1 = cc[1];
     };
+    auto b1_group = [&](uint32_t base, const uint2 e[8]) {       // bins base .. base+7
+        if (mode == 2 && base + 8 <= i1) {                       // merged and inside the chunk: nothing can close the stretch
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) { const CodeEntry ce{e[j].x, e[j].y >> 16}; Tm += step_range(ce, &Rm); }
+        } else if (mode != 3) {
+            for (uint32_t j = 0; j < 8; j++) if (base + j < n) one(base + j, e[j]);
+        }
+    };
     // a slice's records are padded with no-ops to a multiple of 8, its codes to a multiple of 16
     uint32_t i = i0;
-    U4 v0, v1, v2, v3;
-    if (i + 32 <= i1) {
-        const U4 *q = reinterpret_cast<const U4 *>(r + i);
-        v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3];
-    }
-    for (; i + 32 <= i1; i += 32) {                              // a cache line of records per trip, the next one in flight
-        U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-        if (i + 64 <= i1) {
-            const U4 *q = reinterpret_cast<const U4 *>(r + i + 32);
-            n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
+    if (i0 < n) {
+        U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+        if (i + 32 <= i1) {
+            const U4 *q = reinterpret_cast<const U4 *>(r + i);
+            v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3];
         }
-        U4 a, b;
-        eight(v0, a.x, a.y); eight(v1, a.z, a.w); eight(v2, b.x, b.y); eight(v3, b.z, b.w);
-        *reinterpret_cast<U4 *>(ro + i) = a;
-        *reinterpret_cast<U4 *>(ro + i + 16) = b;
-        v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+        for (; i + 32 <= i1; i += 32) {                          // a cache line of records per trip, the next one in flight
+            U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
+            if (i + 64 <= i1) {
+                const U4 *q = reinterpret_cast<const U4 *>(r + i + 32);
+                n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
+            }
+            U4 a, b;
+            uint2 e[8];
+            eight(v0, a.x, a.y, e); b1_group(i, e);
+            eight(v1, a.z, a.w, e); b1_group(i + 8, e);
+            eight(v2, b.x, b.y, e); b1_group(i + 16, e);
+            eight(v3, b.z, b.w, e); b1_group(i + 24, e);
+            *reinterpret_cast<U4 *>(ro + i) = a;
+            *reinterpret_cast<U4 *>(ro + i + 16) = b;
+            v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+        }
+        for (; i < i1; i += 16) {
+            const U4 *q = reinterpret_cast<const U4 *>(r + i);
+            const U4 nop{AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2};
+            const U4 t0 = q[0], t1 = i + 8 < i1 ? q[1] : nop;
+            U4 a;
+            uint2 e[8];
+            eight(t0, a.x, a.y, e); b1_group(i, e);
+            eight(t1, a.z, a.w, e); b1_group(i + 8, e);
+            *reinterpret_cast<U4 *>(ro + i) = a;
+        }
+        if (mode == 0) mode = 3;                                 // no LPS in the chunk: no stretch opens here (first stays kNone)
+        // past the chunk: on through the next chunk's bins until the stretch closes (codes not written: not this lane's)
+        for (i = limit; mode != 3 && i < n; i += 8) {
+            uint32_t c0, c1;
+            uint2 e[8];
+            eight(*reinterpret_cast<const U4 *>(r + i), c0, c1, e);
+            for (uint32_t j = 0; j < 8; j++) if (i + j < n && mode != 3) one(i + j, e[j]);
+        }
     }
-    for (; i < i1; i += 16) {
-        const U4 *q = reinterpret_cast<const U4 *>(r + i);
-        const U4 nop{AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2};
-        const U4 t0 = q[0], t1 = i + 8 < i1 ? q[1] : nop;
-        U4 a;
-        eight(t0, a.x, a.y); eight(t1, a.z, a.w);
-        *reinterpret_cast<U4 *>(ro + i) = a;
+    if (o.first != kNone) {
+        o.end = mode != 3 ? n : end;                             // not closed: ran to the end of the slice
+        for (uint32_t q = 0; q < 4; q++) {                       // once merged, Rm / Tm carried on for all four candidates
+            o.t_exit[q] = T[q] + (merged ? Tm : 0u);
+            o.r_exit[q] = uint16_t(merged ? Rm : R[q]);
+        }
     }
+    stretch[gc] = o;
 }
 
 // ------------------------------------------------------------------ phases B1, B2, C
@@ -764,7 +844,7 @@ inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 // caller's context count; the kernels index it by the dense count, which is known after the census
 // (the one host round trip of the path: four bytes, to size the later launches).
 struct ResolveLayout {
-    uint64_t lbits, lend, est, meta, total;
+    uint64_t lbits, lend, est, stretch, meta, total;
 };
 static inline ResolveLayout resolve_layout(size_t n_slices, uint32_t ns, const avr_chunk_plan *pl) {
     ResolveLayout L;
@@ -774,18 +854,22 @@ static inline ResolveLayout resolve_layout(size_t n_slices, uint32_t ns, const a
     L.lbits = take(uint64_t(pl->total_chunks + 64) * 128);       // + 64 chunks: the chains read a few chunks ahead, unconditionally
     L.lend = take(uint64_t(pl->total_chunks + 64) * ns * 2 + 256) + 128;     // a pad in front: k_k1p_ctxchain reads lend[-1]
     L.est = take(uint64_t(pl->total_chunks) * ((ns + 3) / 4) * 4 + 16);
+    L.stretch = take(uint64_t(pl->total_chunks) * sizeof(Stretch));
     L.meta = take(256 + 2048 + 2048 + kTnBytes);                 // used[32] + n_dense, table[1024], index[1024], tn
     L.total = at;
     return L;
 }
 
 static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const uint8_t *init_states,
-                                 const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, int32_t *status, uint8_t *final_states) {
+                                 const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, int32_t *status, uint8_t *final_states,
+                                 uint32_t max_stretch, const Stretch **stretch_out) {
     const uint32_t ns = p.ns_full;
     const ResolveLayout L = resolve_layout(n_slices, ns, pl);
     uint32_t *lbits = reinterpret_cast<uint32_t *>(w + L.lbits);
     uint16_t *lend = reinterpret_cast<uint16_t *>(w + L.lend);
     uint8_t *est = w + L.est;
+    Stretch *stretch = reinterpret_cast<Stretch *>(w + L.stretch);
+    if (stretch_out) *stretch_out = stretch;
     uint32_t *used = reinterpret_cast<uint32_t *>(w + L.meta);   // [32], then n_dense
     uint32_t *n_dense = used + 32;
     uint16_t *table = reinterpret_cast<uint16_t *>(w + L.meta + 256), *index = table + 1024;
@@ -816,33 +900,43 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
                            pl->total_chunks, status, lbits, lend);
     }
     if (n_states > 0) {
-        const uint32_t groups = (n_states + kChainLanes - 1) / kChainLanes;
+        // lanes per wave: enough waves to hide the chain's latency (about two per SIMD), but not so few lanes per wave that
+        // issuing the waves becomes the limit (measured on 512 slices x 86 contexts: 8 lanes 0.77 ms, 16 0.44, 22 .. 64 0.29)
+        uint32_t chain_lanes = uint32_t((uint64_t(n_slices) * n_states + 2047) / 2048);
+        chain_lanes = chain_lanes < kChainLanes ? kChainLanes : chain_lanes > 64 ? 64 : chain_lanes;
+        if (const char *f = getenv("AVR_CHAIN_LANES")) {         // tuning switch
+            const uint32_t v = uint32_t(strtoul(f, nullptr, 10));
+            if (v >= 1 && v <= 64) chain_lanes = v;
+        }
+        const uint32_t groups = (n_states + chain_lanes - 1) / chain_lanes;
         hipLaunchKernelGGL(k_k1p_ctxchain, dim3((n_slices * groups + kChainWaves - 1) / kChainWaves), dim3(64 * kChainWaves), 0, s, p,
-                           n_slices, groups, status, tn, lbits, lend, init_states, est, final_states);
+                           n_slices, groups, chain_lanes, status, tn, lbits, lend, init_states, est, final_states);
     }
-    // the waves of a workgroup share the two tables; each has its own state rows: as many waves as 60 KiB hold (1 .. 4)
+    // the waves of a workgroup share the two tables (12 KiB, static); each has its own state rows: as many waves as fit (1 .. 4)
     const uint32_t per_wave = ((n_states + 8) / 4) * 256;
-    const uint32_t replay_waves = per_wave * 4 <= 60 * 1024 ? 4 : per_wave * 2 <= 60 * 1024 ? 2 : 1;
-    const uint32_t replay_lds = kReplayTable * 4 + replay_waves * per_wave;
-    if (replay_lds > 60 * 1024) {
+    const uint32_t replay_waves = per_wave * 4 <= 48 * 1024 ? 4 : per_wave * 2 <= 48 * 1024 ? 2 : 1;
+    const uint32_t replay_lds = replay_waves * per_wave;
+    if (replay_lds > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_k1p_replay), hipFuncAttributeMaxDynamicSharedMemorySize, int(replay_lds));
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_k1p_replay, dim3((pl->total_chunks + 64 * replay_waves - 1) / (64 * replay_waves)), dim3(64 * replay_waves),
-                       replay_lds, s, p, pl->total_chunks, reinterpret_cast<const uint32_t *>(est), res, status);
+                       replay_lds, s, p, pl->total_chunks, reinterpret_cast<const uint32_t *>(est), res, status, stretch, max_stretch);
     return hipGetLastError();
 }
 
 // Phases B-D: resolved codes -> bytes.  `w` is workspace for stretches, entries, totals, digit sums.
+// `have` != nullptr: the stretch summaries (phase B1) have been made already, by k_k1p_replay.
 static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, const avr_chunk_plan *pl, uint8_t *w,
                               const uint8_t *res, uint32_t max_stretch, uint8_t *out, const uint64_t *out_off,
-                              uint32_t *out_len, int32_t *status) {
-    Stretch *st = reinterpret_cast<Stretch *>(w);            w += up256(uint64_t(pl->total_chunks) * sizeof(Stretch));
+                              uint32_t *out_len, int32_t *status, const Stretch *have = nullptr) {
+    Stretch *st_own = reinterpret_cast<Stretch *>(w);        w += up256(uint64_t(pl->total_chunks) * sizeof(Stretch));
+    const Stretch *st = have ? have : st_own;
     Entry *en = reinterpret_cast<Entry *>(w);                w += up256(uint64_t(pl->total_chunks) * sizeof(Entry));
     SliceTotals *tot = reinterpret_cast<SliceTotals *>(w);   w += up256(n_slices * sizeof(SliceTotals));
     uint32_t *S = reinterpret_cast<uint32_t *>(w);
     const uint32_t chunk_blocks = (pl->total_chunks + 255) / 256;
-    hipLaunchKernelGGL(k_k1p_b1, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, status, st, max_stretch);
+    if (!have) hipLaunchKernelGGL(k_k1p_b1, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, status, st_own, max_stretch);
     hipLaunchKernelGGL(k_k1p_b2, dim3(n_slices), dim3(256), 0, s, p, status, st, en, tot);
     hipLaunchKernelGGL(k_k1p_zero, dim3(n_slices), dim3(256), 0, s, p, tot, S);
     hipLaunchKernelGGL(k_k1p_c, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
@@ -879,10 +973,11 @@ hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
     uint8_t *res = w;                                        w += up256(pl->res_total + 32);
     const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
                  pl->dig_off, 0, n_states, nullptr, nullptr};
-    hipError_t e = launch_resolve(s, p, n_slices, init_states, pl, w, res, status, final_states);
+    const Stretch *st = nullptr;
+    hipError_t e = launch_resolve(s, p, n_slices, init_states, pl, w, res, status, final_states, kMaxStretch, &st);
     if (e != hipSuccess) return e;
     w += resolve_ws_bytes(n_slices, n_states, pl);
-    e = launch_code(s, p, n_slices, pl, w, res, kMaxStretch, out, out_off, out_len, status);
+    e = launch_code(s, p, n_slices, pl, w, res, kMaxStretch, out, out_off, out_len, status, st);
     if (e != hipSuccess) return e;
     // slices the scheme declined (status AVR_SLICE_RETRY_SERIAL) are coded by the serial kernel
     return launch_cabac_encode(false, s, recs, rec_off, n_bins, nullptr, n_slices, init_states, n_states, out, out_off,
@@ -899,7 +994,8 @@ hipError_t launch_k1p_resolve(hipStream_t s, const uint16_t *recs, const uint64_
     if (n_slices == 0) return hipSuccess;
     const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
                  pl->dig_off, 0, n_states, nullptr, nullptr};
-    return launch_resolve(s, p, n_slices, init_states, pl, static_cast<uint8_t *>(workspace), codes, status, final_states);
+    return launch_resolve(s, p, n_slices, init_states, pl, static_cast<uint8_t *>(workspace), codes, status, final_states, kMaxStretch,
+                          nullptr);
 }
 // ... and phases B-D from resolved codes (no stretch is declined for its length here: a stretch without an
 // LPS is simply walked to its end by one lane); a slice phase D hands back is coded by k_cabac_encode_codes
