@@ -1,25 +1,24 @@
 // K1p kernels: intra-slice parallel CABAC encode for batches of few, long slices.
 // The algorithm and the per-lane functions of phases B-D are in avr_k1p.h; this file maps
-// them to lanes and adds phase A (context-state resolution), which is a per-slice stable
-// counting sort by context followed by one state chain per (slice, context):
+// them to lanes and adds phase A (context-state resolution; see "phase A" below):
 //
-//   k_k1p_hist      A1  workgroup per sort block    per-block count of every context
-//   k_k1p_scan      A2  workgroup per slice         run start of every context, block offsets
-//   k_k1p_scatter   A3  wave per sort block         stable rank (ballot multisplit) -> sorted order
-//   k_k1p_spec      A4a lane per sorted segment     walk the entered run from the two extreme states
-//   k_k1p_link      A4b lane per sorted segment     true entry state of every segment
-//   k_k1p_chain     A4c lane per sorted segment     state before each bin (cabac_code.h:43-47) -> resolved codes
-//   k_k1p_entry     A5a thread per 4 contexts       state of every context at the start of every chunk
-//   k_k1p_replay    A5b lane per chunk              resolved code of every bin, in stream order
-//   k_k1p_b1        B1  lane per chunk              stretch summaries for the 4 entry quarters
-//   k_k1p_b2        B2  lane per slice              chain the summaries: entry range + bit position
-//   k_k1p_zero          workgroup per slice         zero the digit sums that will be used
-//   k_k1p_c         C   lane per chunk              code each stretch, add its digits
-//   k_k1p_d         D   workgroup per slice         finish(), carries (segmented), bytes
+//   k_k1p_census    A   workgroup per 4096 bins      validates every record; which contexts the batch uses
+//   k_k1p_densemap  A   one workgroup                dense numbering of those contexts
+//   k_k1p_tn        A   thread per table entry       state after n = 0..8 bins, per state and bin pattern
+//   k_k1p_local     A   lane per chunk               counting sort of the chunk's bins by context (lane-serial)
+//   k_k1p_ctxchain  A   lane per (slice, context)    state chain through the slice -> state of every context per chunk
+//   k_k1p_replay    A+B1 lane per chunk              resolved code of every bin, in stream order, and the
+//                                                    chunk's stretch summary for the 4 entry quarters
+//   k_k1p_b1        B1  lane per chunk               the same summaries from finished codes (resolved-code entry)
+//   k_k1p_b2        B2  workgroup per slice          chain the summaries: entry range + bit position
+//   k_k1p_zero          workgroup per slice          zero the digit sums that will be used
+//   k_k1p_c         C   lane per chunk               code each stretch, add its digits
+//   k_k1p_d         D   workgroup per slice          finish(), carries (segmented), bytes
+//   k_cabac_encode_codes  lane per slice             serial coder from resolved codes (hand-over of phase D; short slices)
 //
-// Input is the slice-major record layout (a slice's bins must be consecutive for the sort and
-// for the chunk lanes).  Results are byte-identical to k_cabac_encode (tests/test_gpu_k1p.py);
-// a slice the scheme declines (no coded LPS for 16 chunks) is coded by k_cabac_encode itself.
+// Input is the slice-major record layout (a slice's bins must be consecutive for the chunk lanes).
+// Results are byte-identical to k_cabac_encode (tests/test_gpu_k1p.py); a slice the scheme declines
+// (no coded LPS for 16 chunks) is coded by k_cabac_encode itself.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
