@@ -27,6 +27,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "../avr_tables.h"
@@ -124,6 +125,50 @@ class cabac_bin_decoder {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Context identity.  libavcodec hands get() a pointer into its per-slice cabac_state[] and the reference
+// keys its model on that ADDRESS (model_key holds a const void *, recode.cpp:325; the estimators live for the
+// whole file, :1065, :669-672, and libavcodec's array stays where it is, so one address is one context
+// from the first slice to the last).  Nothing else is known about the pointer -- no callback announces the
+// array -- so the recorders number the addresses as they first appear: one table per file, shared by the
+// slices' recorders.  Ids are dense, which is also what the device wants of a selector (fewer state bytes
+// per lane).  Look-up: addresses within 2 KiB of the first one seen (any 1024-byte array holding it) go
+// through a flat table, anything else through a hash map.
+class context_ids {
+  public:
+    int id_of(const uint8_t *state) {
+        const uintptr_t at = reinterpret_cast<uintptr_t>(state) - window_lo_;
+        if (at < kWindow && near_[at] >= 0) return near_[at];
+        return assign(state);
+    }
+    const uint8_t *pointer_of(int id) const { return pointers_.at(size_t(id)); }
+    int size() const { return int(pointers_.size()); }
+
+  private:
+    static constexpr uintptr_t kWindow = 4096;
+    int assign(const uint8_t *state) {
+        if (pointers_.empty()) {
+            window_lo_ = reinterpret_cast<uintptr_t>(state) - kWindow / 2;
+            near_.assign(kWindow, int16_t(-1));
+        }
+        const uintptr_t at = reinterpret_cast<uintptr_t>(state) - window_lo_;
+        if (at >= kWindow) {
+            auto it = far_.find(state);
+            if (it != far_.end()) return it->second;
+        }
+        if (pointers_.size() >= AVR_MAX_STATES)
+            throw std::invalid_argument("more than " + std::to_string(AVR_MAX_STATES) + " distinct CABAC state addresses in one file");
+        const int id = int(pointers_.size());
+        pointers_.push_back(state);
+        if (at < kWindow) near_[at] = int16_t(id); else far_[state] = id;
+        return id;
+    }
+    uintptr_t window_lo_ = 0;
+    std::vector<int16_t> near_;
+    std::unordered_map<const uint8_t *, int> far_;
+    std::vector<const uint8_t *> pointers_;
+};
+
+// ---------------------------------------------------------------------------------------------
 // compress direction: every decoded bin becomes a range record (what encoder.put would have read)
 class compress_recorder {
   public:
@@ -187,16 +232,15 @@ class compress_recorder {
 // decompress direction: the hook surface of decompressor::cabac_decoder (recode.cpp:1442-1481)
 class decompress_recorder {
   public:
-    // cabac: the block's recoded bytes (recode.cpp:1429-1430); state_base: the slice's first state
-    // byte, context identity is the offset of `state` from it (recode.cpp:325 keys on the address)
-    decompress_recorder(h264_model *model, const uint8_t *cabac, size_t cabac_size, const uint8_t *state_base)
-        : model_(model), decoder_(cabac, cabac + cabac_size), state_base_(state_base) {
+    // cabac: the block's recoded bytes (recode.cpp:1429-1430); ids: the file's table of context addresses
+    decompress_recorder(h264_model *model, const uint8_t *cabac, size_t cabac_size, context_ids *ids)
+        : model_(model), decoder_(cabac, cabac + cabac_size), ids_(ids) {
         model_->reset();                                                                // :1428
         memset(seen_, 0, sizeof seen_);
         memset(init_states_, 0, sizeof init_states_);
     }
     int get(uint8_t *state) {                                                           // :1442-1456
-        const int context = context_of(state);
+        const int context = ids_->id_of(state);
         int symbol;
         if (model_->coding_type == PIP_SIGNIFICANCE_EOB) symbol = std::get<1>(model_->get_model_key(context));   // not coded: implied by the count
         else symbol = decoder_.get(model_->probability_for_state(decoder_.range(), context));
@@ -236,18 +280,13 @@ class decompress_recorder {
     const std::vector<uint16_t> &records() const { return recs_; }
     // the same bins as resolved codes (AVR_CODE_*): what avr_batch_add_slice_codes takes; half the bytes, no state arrays
     const std::vector<uint8_t> &codes() const { return codes_; }
-    const uint8_t *init_states() const { return init_states_; }   // *state as it was at each context's first bin
-    int n_states() const { return n_states_; }                     // highest context touched + 1
+    const uint8_t *init_states() const { return init_states_; }   // *state as it was at each context's first bin in this slice
+    int n_states() const { return n_states_; }                     // highest context id touched + 1
 
   private:
-    int context_of(const uint8_t *state) const {
-        const ptrdiff_t d = state - state_base_;
-        if (d < 0 || d >= AVR_MAX_STATES) throw std::invalid_argument("decompress_recorder: state pointer outside the slice's cabac_state[]");
-        return int(d);
-    }
     h264_model *model_;
     range_decoder decoder_;
-    const uint8_t *state_base_;
+    context_ids *ids_;
     std::vector<uint16_t> recs_;
     std::vector<uint8_t> codes_;
     uint8_t seen_[AVR_MAX_STATES], init_states_[AVR_MAX_STATES];
@@ -358,19 +397,26 @@ struct Recoded {
     }
 };
 
-// Surrogate payloads of the decompress direction (recode.cpp:1534-1551) and their check (:1553-1580)
+// Surrogate payloads of the decompress direction.  The decoder is fed, in place of each coded slice payload,
+// a block of the payload's size that starts with a marker identifying the block (checked again when the
+// decoder hands the bytes to init_decoder) and is filled up with 'X' (recode.cpp:1534-1551).  The marker is
+// the block's sequence number written with SURROGATE_MARKER_BYTES base-255 digits, least significant first,
+// each stored + 1: no zero byte, so no start code or emulation prevention can arise inside it.
 constexpr int SURROGATE_MARKER_BYTES = 8;               // recode.cpp:33
 inline std::string next_surrogate_marker(uint64_t *sequence_number) {
-    uint64_t n = (*sequence_number)++;
-    std::string marker(SURROGATE_MARKER_BYTES, '\x01');
-    for (size_t i = 0; i < marker.size(); i++) { marker[i] = char((n % 255) + 1); n /= 255; }
+    uint64_t value = *sequence_number;
+    *sequence_number += 1;
+    std::string marker;
+    marker.reserve(SURROGATE_MARKER_BYTES);
+    while (marker.size() < size_t(SURROGATE_MARKER_BYTES)) {
+        marker.push_back(char(value % 255 + 1));
+        value /= 255;
+    }
     return marker;
 }
 inline std::string make_surrogate_block(const std::string &marker, size_t size) {
-    if (size < marker.size()) throw std::runtime_error("Invalid coded block size for surrogate: " + std::to_string(size));
-    std::string block = marker;
-    block.resize(size, 'X');
-    return block;
+    if (marker.size() > size) throw std::runtime_error("Invalid coded block size for surrogate: " + std::to_string(size));
+    return marker + std::string(size - marker.size(), 'X');
 }
 
 }  // namespace host

@@ -1,7 +1,7 @@
 // compressor / decompressor / roundtrip: the orchestration of the reference (recode.cpp:1109-1640)
 // around the GPU batches.  Block bookkeeping, literal gaps, skip blocks, surrogate payloads and
-// the tail patch follow the reference line by line in behaviour; what differs is WHEN bins are
-// coded: the recorders collect them per slice and one avr_batch codes all slices of the file at
+// the tail patch behave as the reference's do (the .recode bytes and the error messages are the
+// contract); what differs is WHEN bins are coded: the recorders collect them per slice and one avr_batch codes all slices of the file at
 // the end of run() (legal because nothing reads the coded bytes earlier: recode.cpp:1131,
 // 1352-1363).
 //
@@ -147,17 +147,13 @@ class compressor {                                       // recode.cpp:1109-1316
             if (block_ < 0) return;                      // skipped: hooks off for this slice (:1146-1152)
             c->out_.block[block_].has_size = true;       // :1154
             c->out_.block[block_].size = size;
-            if (!c->state_base_) throw std::runtime_error("compressor: the decoder did not register its state array");
             recorder_.reset(new compress_recorder(&c->model_));   // :1161-1163
-            base_ = c->state_base_;
         }
         ~cabac_decoder() { if (recorder_) c_->pending_.push_back({block_, recorder_->records()}); }
         bool hooked() const { return block_ >= 0; }
         int get(uint8_t *state) {                        // :1182-1186
             const int symbol = decoder_.get(state);      // ::ff_get_cabac on the private context copy
-            const ptrdiff_t context = state - base_;     // context identity is the address (recode.cpp:325)
-            if (context < 0 || context >= AVR_MAX_STATES) throw std::invalid_argument("compressor: state pointer outside cabac_state[]");
-            recorder_->execute_symbol(symbol, int(context));
+            recorder_->execute_symbol(symbol, c_->contexts_.id_of(state));   // context identity is the address (recode.cpp:325)
             return symbol;
         }
         int get_bypass() {                               // :1188-1192
@@ -180,40 +176,50 @@ class compressor {                                       // recode.cpp:1109-1316
         cabac_bin_decoder decoder_;
         int block_ = -1;
         std::unique_ptr<compress_recorder> recorder_;
-        const uint8_t *base_ = nullptr;
     };
 
-    // the decoder's cabac_state[] for the slices to come (stands for the address arithmetic on
-    // libavcodec's H264SliceContext that a real integration does)
-    void set_state_base(const uint8_t *base) { state_base_ = base; }
     h264_model *get_model() { return &model_; }          // :1276-1278
+    const context_ids &contexts() const { return contexts_; }
     std::map<void *, std::unique_ptr<cabac_decoder>> cabac_contexts;     // :236
 
   private:
-    // :1282-1304; returns the index of the block the recoder fills, or -1 for a skipped slice
+    // What the reference's find_next_coded_block_and_emit_literal does (recode.cpp:1282-1304).  libavcodec hands
+    // over the slice payload it is about to decode; the file bytes read so far and not yet accounted for are
+    // searched for it.  Found (and long enough to carry a surrogate marker later): everything in front of it
+    // becomes a literal block -- present even when empty -- and a block for the recoded payload follows, noting
+    // the parity of the payload's length and its last byte (what the tail patch needs, :1354-1360); the index
+    // of that block is returned.  Not found (the NAL was unescaped on the way) or too short: a skip_coded block
+    // records the size, the bytes stay in the literal stream, and -1 says "leave this slice alone".
     int find_next_coded_block_and_emit_literal(const uint8_t *buf, int size) {
-        const char *hay = original_.data() + prev_coded_block_end_;
-        const size_t hay_len = read_offset_ - prev_coded_block_end_;
-        const char *found = size > 0 ? static_cast<const char *>(memmem(hay, hay_len, buf, size)) : nullptr;
-        if (found && size >= SURROGATE_MARKER_BYTES) {
-            const size_t gap = found - hay;
-            Block lit;
-            lit.has_literal = true;
-            lit.literal.assign(hay, gap);
-            out_.block.push_back(lit);
-            prev_coded_block_end_ += gap + size;
-            Block nb;
-            nb.has_length_parity = true;
-            nb.length_parity = size & 1;
-            if (size > 1) { nb.has_last_byte = true; nb.last_byte.assign(reinterpret_cast<const char *>(buf) + size - 1, 1); }
-            out_.block.push_back(nb);
-            return int(out_.block.size()) - 1;
+        const size_t window_begin = size_t(prev_coded_block_end_), window_end = size_t(read_offset_);
+        size_t where = std::string::npos;
+        if (size >= SURROGATE_MARKER_BYTES) {
+            const void *hit = memmem(original_.data() + window_begin, window_end - window_begin, buf, size_t(size));
+            if (hit) where = size_t(static_cast<const char *>(hit) - original_.data());
         }
-        Block skip;                                      // probably NAL-escaped: leave it in the literal stream
-        skip.has_skip_coded = true; skip.skip_coded = true;
-        skip.has_size = true; skip.size = size;
-        out_.block.push_back(skip);
-        return -1;
+        if (where == std::string::npos) {
+            Block skipped;
+            skipped.has_skip_coded = true;
+            skipped.skip_coded = true;
+            skipped.has_size = true;
+            skipped.size = size;
+            out_.block.push_back(skipped);
+            return -1;
+        }
+        Block in_front;
+        in_front.has_literal = true;
+        in_front.literal = original_.substr(window_begin, where - window_begin);
+        out_.block.push_back(in_front);
+        Block coded;
+        coded.has_length_parity = true;
+        coded.length_parity = (size % 2) != 0;
+        if (size > 1) {
+            coded.has_last_byte = true;
+            coded.last_byte = std::string(1, char(buf[size - 1]));
+        }
+        out_.block.push_back(coded);
+        prev_coded_block_end_ = int(where) + size;
+        return int(out_.block.size()) - 1;
     }
 
     void code_pending() {                                // one K2 batch for the whole file
@@ -239,7 +245,7 @@ class compressor {                                       // recode.cpp:1109-1316
     std::string original_;
     int device_;
     int read_offset_ = 0, prev_coded_block_end_ = 0;
-    const uint8_t *state_base_ = nullptr;
+    context_ids contexts_;                               // one numbering of the state addresses for the whole file
     h264_model model_;
     Recoded out_;
     std::vector<pending> pending_;
@@ -281,52 +287,64 @@ class decompressor {                                     // recode.cpp:1319-1598
         return out;
     }
 
-    int read_packet(uint8_t *buffer_out, int size) {     // :1366-1416
-        uint8_t *p = buffer_out;
-        while (size > 0 && read_index_ < int(in_.block.size())) {
-            if (read_block_.empty()) {
-                const Block &block = in_.block[read_index_];
-                if (int(block.has_literal) + int(block.has_cabac) + int(block.has_skip_coded) != 1)
-                    throw std::runtime_error("Invalid input block: must have exactly one type");
-                if (block.has_literal) {
-                    blocks_[read_index_].out_bytes = block.literal;
-                    blocks_[read_index_].done = true;
-                    read_block_ = block.literal;
-                } else if (block.has_cabac) {
-                    blocks_[read_index_].coded = true;
-                    blocks_[read_index_].surrogate_marker = next_surrogate_marker(&surrogate_marker_sequence_number_);
-                    blocks_[read_index_].done = false;
-                    if (!block.has_size) throw std::runtime_error("CABAC block requires size field.");
-                    if (block.has_length_parity && block.has_last_byte && !block.last_byte.empty()) {
-                        blocks_[read_index_].length_parity = block.length_parity;
-                        blocks_[read_index_].last_byte = uint8_t(block.last_byte[0]);
-                    }
-                    read_block_ = make_surrogate_block(blocks_[read_index_].surrogate_marker, size_t(block.size));
-                } else if (block.has_skip_coded && block.skip_coded) {
-                    blocks_[read_index_].coded = true;
-                    blocks_[read_index_].done = true;
-                } else {
-                    throw std::runtime_error("Unknown input block type");
-                }
+    // The stream the decoder reads (decompressor::read_packet, recode.cpp:1366-1416): the blocks in order, a
+    // literal as it is, a coded block as a surrogate payload of the recorded size, a skip_coded block as nothing
+    // (its bytes are part of the next literal).  A block is classified when the reader first reaches it.
+    int read_packet(uint8_t *buffer_out, int size) {
+        int written = 0;
+        while (written < size) {
+            if (feed_at_ == feed_.size()) {              // the current block is used up: open the next one that has bytes
+                if (read_index_ >= int(in_.block.size())) break;
+                feed_ = open_block(read_index_++);
+                feed_at_ = 0;
+                continue;
             }
-            if (size_t(read_offset_) < read_block_.size()) {
-                const int n = int(read_block_.copy(reinterpret_cast<char *>(p), size, read_offset_));
-                read_offset_ += n; p += n; size -= n;
-            }
-            if (size_t(read_offset_) >= read_block_.size()) { read_block_.clear(); read_offset_ = 0; read_index_++; }
+            const size_t n = std::min(feed_.size() - feed_at_, size_t(size - written));
+            memcpy(buffer_out + written, feed_.data() + feed_at_, n);
+            feed_at_ += n;
+            written += int(n);
         }
-        return int(p - buffer_out);
+        return written;
     }
 
+  private:
+    // what block `index` contributes to the stream; sets up its block_state
+    std::string open_block(int index) {
+        const Block &block = in_.block[size_t(index)];
+        block_state &state = blocks_[size_t(index)];
+        const int kinds = (block.has_literal ? 1 : 0) + (block.has_cabac ? 1 : 0) + (block.has_skip_coded ? 1 : 0);
+        if (kinds != 1) throw std::runtime_error("Invalid input block: must have exactly one type");
+        if (block.has_literal) {
+            state.out_bytes = block.literal;
+            state.done = true;
+            return block.literal;
+        }
+        if (block.has_skip_coded) {
+            if (!block.skip_coded) throw std::runtime_error("Unknown input block type");
+            state.coded = true;
+            state.done = true;
+            return std::string();
+        }
+        if (!block.has_size) throw std::runtime_error("CABAC block requires size field.");
+        state.coded = true;
+        state.done = false;
+        state.surrogate_marker = next_surrogate_marker(&surrogate_marker_sequence_number_);
+        if (block.has_length_parity && block.has_last_byte && !block.last_byte.empty()) {
+            state.length_parity = block.length_parity ? 1 : 0;
+            state.last_byte = uint8_t(block.last_byte[0]);
+        }
+        return make_surrogate_block(state.surrogate_marker, size_t(block.size));
+    }
+
+  public:
     class cabac_decoder {                                // :1418-1527
       public:
         cabac_decoder(decompressor *d, const uint8_t *buf, int size) : d_(d) {
             index_ = d->recognize_coded_block(buf, size);
             const Block &block = d->in_.block[index_];
             if (block.has_cabac) {
-                if (!d->state_base_) throw std::runtime_error("decompressor: the decoder did not register its state array");
                 recorder_.reset(new decompress_recorder(&d->model_, reinterpret_cast<const uint8_t *>(block.cabac.data()),
-                                                        block.cabac.size(), d->state_base_));
+                                                        block.cabac.size(), &d->contexts_));
             } else if (!(block.has_skip_coded && block.skip_coded)) {
                 throw std::runtime_error("Expected CABAC block.");
             }
@@ -347,26 +365,29 @@ class decompressor {                                     // recode.cpp:1319-1598
         std::unique_ptr<decompress_recorder> recorder_;
     };
 
-    void set_state_base(const uint8_t *base) { state_base_ = base; }
     h264_model *get_model() { return &model_; }          // :1528-1530
     std::map<void *, std::unique_ptr<cabac_decoder>> cabac_contexts;
 
   private:
-    int recognize_coded_block(const uint8_t *buf, int size) {      // :1553-1580
-        while (!blocks_[next_coded_block_].coded) {
-            if (next_coded_block_ >= read_index_) throw std::runtime_error("Coded block expected, but not recorded in the compressed data.");
-            next_coded_block_++;
+    // The decoder announces a slice payload (init_decoder): which block is it?  Coded blocks -- recoded or
+    // skipped -- come up in the order the reader produced them, so it is the next coded one among the blocks the
+    // reader has opened; its size must be the announced one, and a recoded block must begin with the marker its
+    // surrogate was given (decompressor::recognize_coded_block, recode.cpp:1553-1580).
+    int recognize_coded_block(const uint8_t *buf, int size) {
+        int index = next_coded_block_;
+        for (;; index++) {
+            if (index >= read_index_) throw std::runtime_error("Coded block expected, but not recorded in the compressed data.");
+            if (blocks_[size_t(index)].coded) break;
         }
-        const int index = next_coded_block_++;
-        const Block &block = in_.block[index];
+        next_coded_block_ = index + 1;
+        const Block &block = in_.block[size_t(index)];
+        if (!block.has_cabac && !block.has_skip_coded) throw std::runtime_error("Internal error: expected coded block.");
+        if (block.size != size)
+            throw std::runtime_error(block.has_cabac ? "Invalid surrogate block size." : "Invalid skip_coded block size.");
         if (block.has_cabac) {
-            if (block.size != size) throw std::runtime_error("Invalid surrogate block size.");
-            const std::string header(reinterpret_cast<const char *>(buf), blocks_[index].surrogate_marker.size());
-            if (blocks_[index].surrogate_marker != header) throw std::runtime_error("Invalid surrogate marker in coded block.");
-        } else if (block.has_skip_coded) {
-            if (block.size != size) throw std::runtime_error("Invalid skip_coded block size.");
-        } else {
-            throw std::runtime_error("Internal error: expected coded block.");
+            const std::string &marker = blocks_[size_t(index)].surrogate_marker;
+            if (size_t(size) < marker.size() || memcmp(buf, marker.data(), marker.size()) != 0)
+                throw std::runtime_error("Invalid surrogate marker in coded block.");
         }
         return index;
     }
@@ -395,12 +416,13 @@ class decompressor {                                     // recode.cpp:1319-1598
     struct pending { int index; std::vector<uint8_t> codes; };
     int device_;
     Recoded in_;
-    int read_index_ = 0, read_offset_ = 0;
-    std::string read_block_;
+    int read_index_ = 0;                                 // blocks the reader has opened
+    std::string feed_;                                   // bytes of the block being read
+    size_t feed_at_ = 0;
     std::vector<block_state> blocks_;
     uint64_t surrogate_marker_sequence_number_ = 1;      // :1592
     int next_coded_block_ = 0;
-    const uint8_t *state_base_ = nullptr;
+    context_ids contexts_;                               // one numbering of the state addresses for the whole file
     h264_model model_;
     std::vector<pending> pending_;
 };

@@ -15,6 +15,25 @@ using namespace avr::host;
 
 namespace {
 
+// Where the decoder's state bytes live.  The hook surface only ever shows their ADDRESSES (recode.cpp:156, 325), so the
+// tests place them differently and expect the same output: layout 0 = one 1024-byte array (libavcodec's cabac_state[]),
+// 1 = two separately allocated halves, the upper one first in memory and far from the lower, 2 = every context in a
+// 64-byte cell of its own.
+int g_state_layout = 0;
+struct state_store {
+    std::vector<uint8_t> a, b;
+    std::vector<uint8_t *> at;                            // at[ctx] = address of context ctx's state byte
+    state_store() : at(1024) {
+        if (g_state_layout == 0) { a.resize(1024); for (int i = 0; i < 1024; i++) at[i] = &a[i]; }
+        else if (g_state_layout == 1) {
+            b.resize(512 + (1 << 20)); a.resize(512);
+            for (int i = 0; i < 512; i++) { at[i] = &a[i]; at[512 + i] = &b[(1 << 20) - 7 + i]; }
+        } else { a.resize(1024 * 64); for (int i = 0; i < 1024; i++) at[i] = &a[size_t(64) * ((i * 389) % 1024) + 5]; }
+    }
+    void load(const uint8_t *init) { for (int i = 0; i < 1024; i++) *at[i] = init[i]; }
+    int context_of(const uint8_t *p) const { for (int i = 0; i < 1024; i++) if (at[i] == p) return i; return -1; }
+};
+
 struct slice_desc {
     size_t offset, size;          // where the slice payload sits in the file
     const uint16_t *recs;         // bin | selector << 1 of every bin the slice decodes to
@@ -30,7 +49,7 @@ struct slice_feeder : stream_decoder {
     compressor *c = nullptr;
     decompressor *d = nullptr;
     size_t mismatches = 0, hooked = 0;
-    uint8_t cabac_state[1024];
+    state_store cabac_state;
 
     void decode_video(hooks *h, int (*read_packet)(void *, uint8_t *, int), void *opaque) override {
         std::vector<uint8_t> data, chunk(1 << 16);
@@ -39,12 +58,10 @@ struct slice_feeder : stream_decoder {
             if (got <= 0) break;
             data.insert(data.end(), chunk.begin(), chunk.begin() + got);
         }
-        if (c) c->set_state_base(cabac_state);
-        if (d) d->set_state_base(cabac_state);
         int ctx_identity = 0;                             // stands for the one CABACContext of a single-threaded decode
         for (const slice_desc &s : slices) {
             if (s.offset + s.size > data.size()) throw std::runtime_error("feeder: slice outside the stream");
-            memcpy(cabac_state, s.init_states, sizeof cabac_state);
+            cabac_state.load(s.init_states);
             std::vector<uint8_t> payload(data.begin() + s.offset, data.begin() + s.offset + s.size);
             if (s.escaped && !payload.empty()) payload[payload.size() / 2] ^= 0x55;
             void *dec = h->cabac.init_decoder(h->opaque, &ctx_identity, payload.data(), int(payload.size()));
@@ -53,7 +70,7 @@ struct slice_feeder : stream_decoder {
             for (size_t i = 0; i < s.n; i++) {
                 const int bin = s.recs[i] & 1, sel = (s.recs[i] >> 1) & 0x7ff;
                 int got;
-                if (sel < 1024) got = h->cabac.get(dec, &cabac_state[sel]);
+                if (sel < 1024) got = h->cabac.get(dec, cabac_state.at[sel]);
                 else if (sel == 1024) got = h->cabac.get_bypass(dec);
                 else got = h->cabac.get_terminate(dec);
                 mismatches += got != bin;
@@ -76,9 +93,9 @@ inline int ctx_last(int cat, int i) { return 300 + (cat % 5) * 16 + std::min(i, 
 inline int ctx_abs(int cat) { return 400 + cat % 5; }
 
 struct syntax_walker {
-    hooks *h; void *dec; uint8_t *cabac_state;
+    hooks *h; void *dec; state_store *cabac_state;
     std::vector<uint8_t> bins;                            // every bin the hooks returned, in order
-    int get(int ctx) { const int b = h->cabac.get(dec, &cabac_state[ctx]); bins.push_back(uint8_t(b)); return b; }
+    int get(int ctx) { const int b = h->cabac.get(dec, cabac_state->at[ctx]); bins.push_back(uint8_t(b)); return b; }
     int bypass() { const int b = h->cabac.get_bypass(dec); bins.push_back(uint8_t(b)); return b; }
     int terminate() { const int b = h->cabac.get_terminate(dec); bins.push_back(uint8_t(b)); return b; }
 
@@ -116,7 +133,7 @@ struct block_feeder : stream_decoder {
     compressor *c = nullptr;
     decompressor *d = nullptr;
     std::vector<uint8_t> bins;
-    uint8_t cabac_state[1024];
+    state_store cabac_state;
     void decode_video(hooks *h, int (*read_packet)(void *, uint8_t *, int), void *opaque) override {
         std::vector<uint8_t> data, chunk(1 << 16);
         for (;;) {
@@ -124,15 +141,13 @@ struct block_feeder : stream_decoder {
             if (got <= 0) break;
             data.insert(data.end(), chunk.begin(), chunk.begin() + got);
         }
-        if (c) c->set_state_base(cabac_state);
-        if (d) d->set_state_base(cabac_state);
         int ctx_identity = 0;
         for (const block_slice &s : slices) {
             if (s.offset + s.size > data.size()) throw std::runtime_error("feeder: slice outside the stream");
-            memcpy(cabac_state, s.init_states, sizeof cabac_state);
+            cabac_state.load(s.init_states);
             void *dec = h->cabac.init_decoder(h->opaque, &ctx_identity, data.data() + s.offset, int(s.size));
             if (!dec) throw std::runtime_error("feeder: slice not hooked");
-            syntax_walker w{h, dec, cabac_state, {}};
+            syntax_walker w{h, dec, &cabac_state, {}};
             w.slice(s.frame_num, s.mb_w, s.mb_h, s.blocks, s.n_blocks);
             bins.insert(bins.end(), w.bins.begin(), w.bins.end());
         }
@@ -142,14 +157,14 @@ struct block_feeder : stream_decoder {
 // CPU-only drivers over the two recorders (no GPU batch: the test codes the records with the oracle)
 struct cpu_compress_driver {
     h264_model model_;
-    const uint8_t *state_base = nullptr;
+    context_ids ids;
     std::vector<uint16_t> recs;                           // K2 records of all slices
     std::vector<uint64_t> rec_end;                        // running end per slice
     struct cabac_decoder {
         cabac_decoder(cpu_compress_driver *d, const uint8_t *buf, int size) : d_(d), dec_(buf, size_t(size)), rec_(&d->model_) {}
         ~cabac_decoder() { d_->recs.insert(d_->recs.end(), rec_.records().begin(), rec_.records().end()); d_->rec_end.push_back(d_->recs.size()); }
         bool hooked() const { return true; }
-        int get(uint8_t *state) { const int s = dec_.get(state); rec_.execute_symbol(s, int(state - d_->state_base)); return s; }
+        int get(uint8_t *state) { const int s = dec_.get(state); rec_.execute_symbol(s, d_->ids.id_of(state)); return s; }
         int get_bypass() { const int s = dec_.get_bypass(); rec_.execute_symbol(s, kKeyBypass); return s; }
         int get_terminate() { const int s = dec_.get_terminate() != 0; rec_.execute_symbol(s, kKeyTerminate); return s; }
         void begin_coding_type(CodingType ct, int z, int p0, int p1) { rec_.begin_coding_type(ct, z, p0, p1); }
@@ -162,13 +177,13 @@ struct cpu_compress_driver {
 
 struct cpu_decompress_driver {
     h264_model model_;
-    const uint8_t *state_base = nullptr;
+    context_ids ids;
     const uint8_t *recoded = nullptr; const uint64_t *recoded_off = nullptr; size_t next = 0;   // per-slice recoded bytes
     std::vector<uint16_t> recs;                           // K1 records of all slices
     std::vector<uint64_t> rec_end;
     struct cabac_decoder {
         cabac_decoder(cpu_decompress_driver *d, const uint8_t *, int)
-            : d_(d), rec_(&d->model_, d->recoded + d->recoded_off[d->next], size_t(d->recoded_off[d->next + 1] - d->recoded_off[d->next]), d->state_base) { d->next++; }
+            : d_(d), rec_(&d->model_, d->recoded + d->recoded_off[d->next], size_t(d->recoded_off[d->next + 1] - d->recoded_off[d->next]), &d->ids) { d->next++; }
         ~cabac_decoder() { d_->recs.insert(d_->recs.end(), rec_.records().begin(), rec_.records().end()); d_->rec_end.push_back(d_->recs.size()); }
         bool hooked() const { return true; }
         int get(uint8_t *state) { return rec_.get(state); }
@@ -194,15 +209,14 @@ struct model_args {
 template <class Driver>
 int model_run_with(Driver &drv, model_args *a) {
     hooks h = hook_adapter<Driver>::make(&drv);
-    uint8_t cabac_state[1024];
-    drv.state_base = cabac_state;
+    state_store cabac_state;
     int ctx_identity = 0;
     size_t n_bins = 0;
     for (size_t i = 0; i < a->n_slices; i++) {
-        memcpy(cabac_state, a->init_states + 1024 * i, sizeof cabac_state);
+        cabac_state.load(a->init_states + 1024 * i);
         const uint8_t *buf = a->payload + a->payload_off[i];
         void *dec = h.cabac.init_decoder(h.opaque, &ctx_identity, buf, int(a->payload_off[i + 1] - a->payload_off[i]));
-        syntax_walker w{&h, dec, cabac_state, {}};
+        syntax_walker w{&h, dec, &cabac_state, {}};
         auto keep_bins = [&] { for (uint8_t b : w.bins) { if (n_bins < a->bins_cap) a->bins_out[n_bins] = b; n_bins++; } *a->n_bins_out = n_bins; };
         try {
             w.slice(a->spec[3 * i], a->spec[3 * i + 1], a->spec[3 * i + 2], a->blocks + a->block_off[i], size_t(a->block_off[i + 1] - a->block_off[i]));
@@ -211,6 +225,11 @@ int model_run_with(Driver &drv, model_args *a) {
     }
     drv.cabac_contexts.clear();                           // the last decoder hands its records over
     *a->n_bins_out = n_bins;
+    if (a->decompress)                                    // K1 records number the contexts by first appearance: back to offsets in cabac_state[]
+        for (uint16_t &r : drv.recs) {
+            const int sel = r >> 1;
+            if (sel < 1024) r = uint16_t((r & 1) | (cabac_state.context_of(drv.ids.pointer_of(sel)) << 1));
+        }
     for (size_t i = 0; i < drv.recs.size() && i < a->recs_cap; i++) a->recs_out[i] = drv.recs[i];
     for (size_t i = 0; i < drv.rec_end.size(); i++) a->rec_end_out[i] = drv.rec_end[i];
     return drv.recs.size() <= a->recs_cap && n_bins <= a->bins_cap ? 0 : 2;
@@ -235,6 +254,8 @@ int guarded(int (*f)(void *), void *arg, char *err, size_t err_cap) {
 }  // namespace
 
 extern "C" {
+
+void t_set_state_layout(int layout) { g_state_layout = layout; }
 
 // ---- units
 void t_range_decode(const uint8_t *bytes, size_t len, const uint16_t *recs, size_t n, uint8_t *bins_out) {

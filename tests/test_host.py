@@ -180,11 +180,24 @@ def test_roundtrip_of_a_file_of_recorded_slices(host, oracle, avr):
     comp_len = ctypes.c_size_t(0)
     stats = np.zeros(2, np.uint64)
     err = ctypes.create_string_buffer(512)
-    rc = host.t_roundtrip(P(fbuf), ctypes.c_size_t(len(data)), ctypes.c_size_t(len(recs_all)), P(np.array(offsets, np.uint64)),
-                          P(np.array(sizes, np.uint64)), P(rec_off), P(np.concatenate(recs_all).astype(np.uint16)),
-                          P(np.concatenate(states_all)), P(np.array(escaped, np.uint8)), P(comp), ctypes.c_size_t(comp.size),
-                          ctypes.byref(comp_len), P(stats), err, ctypes.c_size_t(512))
+    def roundtrip():
+        return host.t_roundtrip(P(fbuf), ctypes.c_size_t(len(data)), ctypes.c_size_t(len(recs_all)), P(np.array(offsets, np.uint64)),
+                                P(np.array(sizes, np.uint64)), P(rec_off), P(np.concatenate(recs_all).astype(np.uint16)),
+                                P(np.concatenate(states_all)), P(np.array(escaped, np.uint8)), P(comp), ctypes.c_size_t(comp.size),
+                                ctypes.byref(comp_len), P(stats), err, ctypes.c_size_t(512))
+    # the decoder's state bytes somewhere else in memory (two distant halves; a cell per context): same .recode bytes,
+    # since all the recorders know of a context is the address of its state byte (recode.cpp:156, :325)
+    elsewhere = []
+    try:
+        for layout in (1, 2):
+            host.t_set_state_layout(layout)
+            assert roundtrip() == 0, err.value.decode()
+            elsewhere.append(comp[:comp_len.value].tobytes())
+    finally:
+        host.t_set_state_layout(0)
+    rc = roundtrip()
     assert rc == 0, err.value.decode()                      # "Compress-decompress roundtrip succeeded"
+    assert all(e == comp[:comp_len.value].tobytes() for e in elsewhere)
     assert stats[0] == 0                                     # every bin the hooks returned is the bin that was coded
     n_hooked = sum(1 for s, e in zip(sizes, escaped) if s >= 8 and not e)
     assert stats[1] == 2 * n_hooked                          # compress pass + decompress pass; tiny / escaped slices are skipped

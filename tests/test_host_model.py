@@ -146,6 +146,37 @@ def test_model_hooks_round_trip_through_both_recorders(host, oracle, density):
     assert sum(len(r) for r in recoded) < sum(len(p) for p in payloads) * 1.2
 
 
+def test_context_identity_is_the_address_wherever_the_state_bytes_live(host, oracle):
+    """The hook surface shows a context only as the address of its state byte (recode.cpp:156, :325); no callback
+    announces libavcodec's array.  The recorders number the addresses as they appear, so the records -- and with them
+    the .recode bytes -- must not depend on where the decoder keeps its states: one 1024-byte array, two halves far
+    apart with the upper one first in memory (the hash path of context_ids), or one 64-byte cell per context."""
+    rng = np.random.default_rng(5)
+    specs, blocks, states, payloads = [], [], [], []
+    for s in range(6):
+        b, rec, _, _ = make_slice(rng, 4, list(range(6)) if s % 2 == 0 else list(range(6, 12)), 0.3)
+        st = rng.integers(0, 126, 1024).astype(np.uint8)
+        data, _, status = oracle.cabac_encode(rec, st)
+        assert status == 0
+        specs += [s // 2, 4, 3]; blocks.append(b); states.append(st); payloads.append(data)
+    cap = 1 << 17
+    runs = []
+    try:
+        for layout in (0, 1, 2):
+            host.t_set_state_layout(layout)
+            k2, bins_c = run_model(host, False, specs, blocks, states, payloads, cap)
+            recoded = [oracle.range_encode(r)[0] for r in k2]
+            k1, bins_d = run_model(host, True, specs, blocks, states, recoded, cap)
+            assert np.array_equal(bins_c, bins_d)
+            runs.append((k2, recoded, k1))
+    finally:
+        host.t_set_state_layout(0)
+    for k2, recoded, k1 in runs[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(k2, runs[0][0]))        # compress: the same range records
+        assert recoded == runs[0][1]                                            # ... hence the same recoded bytes
+        assert all(np.array_equal(a, b) for a, b in zip(k1, runs[0][2]))        # decompress: the same bins on the same contexts
+
+
 @pytest.mark.gpu
 def test_file_round_trip_with_the_model_hooks_firing(host, oracle, avr):
     """recode.cpp:1601-1640 with all eleven hooks in use: K2 codes the queued maps and their counts, the
