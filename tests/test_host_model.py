@@ -10,6 +10,7 @@ Parity unpinned: the reference's model cannot be built here and none of its test
     nonzero-count bits sent ahead of each map);
   * the block-neighbour geometry equals libavcodec's scan8 arithmetic."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -248,6 +249,22 @@ def test_model_errors(host, oracle):
                           P(np.frombuffer(data + b"\0", np.uint8).copy()), P(poff), P(recs), ctypes.c_size_t(recs.size), P(rec_end),
                           P(bins), ctypes.c_size_t(bins.size), ctypes.byref(n), err, ctypes.c_size_t(512))
     assert rc == -1 and b"outside the frame" in err.value
+
+
+def test_block_neighbours_equal_the_reference_table(host):
+    """neighbor_block against the reference's own reverse_scan_8 (recode.cpp:286-319, the table get_neighbor_sub_mb looks
+    the left / upper neighbour up in, :426-478), committed as data: tests/golden/reverse_scan8.json."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reverse_scan8.json")))
+    scan_8, rev = g["scan_8"], g["reverse_scan_8"]
+    out = np.zeros(3, np.int32)
+    for i in range(48):
+        for above in (0, 1):
+            at = scan_8[i] - (8 if above else 1)                 # recode.cpp:447-448 / :463-464
+            idx, left, up = rev[at >> 3][at & 7]
+            assert not (idx == 0 and left and up), "the reference's table has no neighbour here"
+            host.t_neighbor_block(i, above, P(out))
+            assert out.tolist() == [idx, int(left), int(up)], (i, above)
 
 
 def test_block_neighbours_equal_scan8_arithmetic(host):
