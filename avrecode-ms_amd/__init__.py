@@ -94,6 +94,15 @@ SIGNATURES = {
     "avr_batch_get": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
     "avr_batch_get_states": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]),
     "avr_batch_timings": (c_int, [c_void_p, POINTER(c_float)]),
+    "avr_multi_create": (c_void_p, [c_void_p, c_size_t, c_size_t, c_size_t]),
+    "avr_multi_destroy": (None, [c_void_p]),
+    "avr_multi_add_slice_cabac": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
+    "avr_multi_add_slice_range": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "avr_multi_add_slice_codes": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "avr_multi_run": (c_int, [c_void_p]),
+    "avr_multi_get": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
+    "avr_multi_placement": (c_int, [c_void_p, c_size_t]),
+    "avr_multi_load": (c_int, [c_void_p, c_void_p]),
     "avr_pack_tiles_device": (c_int, [c_int, c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                       c_void_p, c_void_p, c_void_p]),
     "avr_cabac_encode_tiles_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
@@ -266,8 +275,67 @@ class Batch:
         return dict(zip(("h2d_ms", "pack_ms", "encode_ms", "d2h_ms"), list(ms)))
 
 
+class MultiBatch:
+    """One batch sharded over several GPUs (avr_multi_*): LPT by bin count, a host thread and an avr_batch per device."""
+
+    def __init__(self, devices, max_slices: int = 1024, max_bins: int = 1 << 24):
+        import numpy as np
+        self._L = lib()
+        self.devices = list(devices)
+        d = np.asarray(self.devices, dtype=np.int32)
+        self._h = self._L.avr_multi_create(d.ctypes.data, d.size, max_slices, max_bins)
+        if not self._h:
+            raise AvrError(self._L.avr_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._L.avr_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def add_slice_cabac(self, recs, init_states) -> int:
+        import numpy as np
+        r = np.ascontiguousarray(recs, dtype=np.uint16)
+        s = np.ascontiguousarray(init_states, dtype=np.uint8)
+        return _check(self._L.avr_multi_add_slice_cabac(self._h, r.ctypes.data, r.size, s.ctypes.data, s.size))
+
+    def add_slice_range(self, recs) -> int:
+        import numpy as np
+        r = np.ascontiguousarray(recs, dtype=np.uint16)
+        return _check(self._L.avr_multi_add_slice_range(self._h, r.ctypes.data, r.size))
+
+    def add_codes(self, codes) -> int:
+        import numpy as np
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        return _check(self._L.avr_multi_add_slice_codes(self._h, c.ctypes.data, c.size))
+
+    def run(self):
+        _check(self._L.avr_multi_run(self._h))
+
+    def get(self, i: int):
+        p, n, st = c_void_p(), c_size_t(), c_int()
+        _check(self._L.avr_multi_get(self._h, i, ctypes.byref(p), ctypes.byref(n), ctypes.byref(st)))
+        return (ctypes.string_at(p.value, n.value) if n.value else b""), st.value
+
+    def placement(self, i: int) -> int:
+        return _check(self._L.avr_multi_placement(self._h, i))
+
+    def load(self):
+        import numpy as np
+        out = np.zeros(len(self.devices), dtype=np.uint64)
+        _check(self._L.avr_multi_load(self._h, out.ctypes.data))
+        return out.tolist()
+
+
 from .device import DeviceWorkload, encode_tiles, plan_tiles, synth_config  # noqa: E402  (torch-backed helpers)
 
-__all__ = ["AvrError", "Batch", "DeviceWorkload", "KIND_CABAC", "KIND_RANGE", "SEL_BYPASS", "SEL_TERMINATE",
+__all__ = ["AvrError", "Batch", "MultiBatch", "DeviceWorkload", "KIND_CABAC", "KIND_RANGE", "SEL_BYPASS", "SEL_TERMINATE",
            "build_native", "cabac_tables", "device_count", "drop_stop_byte", "encode_tiles", "lib",
            "make_cabac_records", "make_range_records", "plan_tiles", "synth_config", "tail_patch"]

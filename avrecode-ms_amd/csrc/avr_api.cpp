@@ -14,6 +14,8 @@
 #include <cstring>
 #include <new>
 #include <numeric>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "avr_internal.h"
@@ -512,6 +514,141 @@ int avr_batch_get_states(avr_batch *b, size_t slice, const uint8_t **states, siz
 int avr_batch_timings(avr_batch *b, float ms[4]) {
     if (!b || !b->ran || !ms) return fail(AVR_ERR_INVALID, "batch has not run");
     memcpy(ms, b->ms, sizeof b->ms);
+    return AVR_OK;
+}
+
+// ------------------------------------------------------------------ one batch over several GPUs
+
+struct avr_multi {
+    std::vector<int> devices;
+    size_t max_slices = 0, max_bins = 0, total_bins = 0;
+    int kind = -1;
+    size_t n_states = 0;
+    bool ran = false;
+    std::vector<uint8_t> store;              // the slices' records / codes, back to back (bytes)
+    std::vector<uint64_t> off;               // n+1 byte offsets into store
+    std::vector<uint32_t> n_bins;
+    std::vector<uint8_t> states;             // n x n_states
+    std::vector<avr_batch *> sub;            // one per entry of devices
+    std::vector<int> place, local;           // slice -> entry of devices, index inside that sub-batch
+    std::vector<uint64_t> load;
+};
+
+avr_multi *avr_multi_create(const int *devices, size_t n_devices, size_t max_slices, size_t max_bins) {
+    if (!devices || n_devices == 0 || n_devices > 64) { fail(AVR_ERR_INVALID, "need 1..64 devices"); return nullptr; }
+    if (max_slices == 0 || max_slices > 0x7fffffffu) { fail(AVR_ERR_INVALID, "max_slices out of range"); return nullptr; }
+    for (size_t i = 0; i < n_devices; i++)
+        if (select_device(devices[i]) != AVR_OK) return nullptr;
+    avr_multi *m = new (std::nothrow) avr_multi;
+    if (!m) { fail(AVR_ERR_NOMEM, "out of host memory"); return nullptr; }
+    m->devices.assign(devices, devices + n_devices);
+    m->max_slices = max_slices;
+    m->max_bins = max_bins;
+    m->off.push_back(0);
+    m->sub.assign(n_devices, nullptr);
+    return m;
+}
+
+void avr_multi_destroy(avr_multi *m) {
+    if (!m) return;
+    for (avr_batch *b : m->sub) avr_batch_destroy(b);
+    delete m;
+}
+
+static int multi_add(avr_multi *m, int kind, const void *data, size_t n, size_t elem, const uint8_t *init_states, size_t n_states) {
+    if (!m) return fail(AVR_ERR_INVALID, "null batch");
+    if (!data && n) return fail(AVR_ERR_INVALID, "null records");
+    if (m->ran) return fail(AVR_ERR_INVALID, "batch already ran");
+    if (m->kind >= 0 && m->kind != kind) return fail(AVR_ERR_INVALID, "a batch holds slices of one kind only");
+    if (n > 0xfffffff0u) return fail(AVR_ERR_INVALID, "slice too long");
+    if (m->n_bins.size() >= m->max_slices) return fail(AVR_ERR_CAPACITY, "batch holds max_slices=%zu slices", m->max_slices);
+    if (m->total_bins + n > m->max_bins) return fail(AVR_ERR_CAPACITY, "batch holds max_bins=%zu records", m->max_bins);
+    if (kind == AVR_KIND_CABAC) {
+        if (n_states > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "n_states %zu > %d", n_states, AVR_MAX_STATES);
+        if (!init_states && n_states) return fail(AVR_ERR_INVALID, "null init_states");
+        if (!m->n_bins.empty() && n_states != m->n_states) return fail(AVR_ERR_INVALID, "all slices of a batch use the same n_states");
+        m->n_states = n_states;
+        m->states.insert(m->states.end(), init_states, init_states + n_states);
+    }
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    m->store.insert(m->store.end(), p, p + n * elem);
+    m->off.push_back(m->store.size());
+    m->n_bins.push_back(uint32_t(n));
+    m->total_bins += n;
+    m->kind = kind;
+    return int(m->n_bins.size()) - 1;
+}
+
+int avr_multi_add_slice_cabac(avr_multi *m, const uint16_t *recs, size_t n, const uint8_t *init_states, size_t n_states) {
+    return multi_add(m, AVR_KIND_CABAC, recs, n, 2, init_states, n_states);
+}
+int avr_multi_add_slice_range(avr_multi *m, const uint16_t *recs, size_t n) { return multi_add(m, AVR_KIND_RANGE, recs, n, 2, nullptr, 0); }
+int avr_multi_add_slice_codes(avr_multi *m, const uint8_t *codes, size_t n) { return multi_add(m, AVR_KIND_CABAC_CODES, codes, n, 1, nullptr, 0); }
+
+int avr_multi_run(avr_multi *m) {
+    if (!m) return fail(AVR_ERR_INVALID, "null batch");
+    if (m->ran) return fail(AVR_ERR_INVALID, "batch already ran");
+    const size_t n = m->n_bins.size(), nd = m->devices.size();
+    // greedy LPT: longest slice first, to the device with the least bins so far (ties: the lower entry)
+    std::vector<uint32_t> by_len(n);
+    std::iota(by_len.begin(), by_len.end(), 0u);
+    std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t a, uint32_t b) { return m->n_bins[a] > m->n_bins[b]; });
+    m->place.assign(n, 0);
+    m->local.assign(n, 0);
+    m->load.assign(nd, 0);
+    std::vector<std::vector<uint32_t>> mine(nd);
+    for (uint32_t i : by_len) {
+        const size_t d = size_t(std::min_element(m->load.begin(), m->load.end()) - m->load.begin());
+        m->place[i] = int(d);
+        m->load[d] += m->n_bins[i];
+        mine[d].push_back(i);
+    }
+    for (size_t d = 0; d < nd; d++) std::sort(mine[d].begin(), mine[d].end());       // each device keeps the caller's order
+    std::vector<int> rc(nd, AVR_OK);
+    std::vector<std::string> err(nd);
+    auto work = [&](size_t d) {
+        if (mine[d].empty()) return;
+        avr_batch *b = avr_batch_create(m->devices[d], mine[d].size(), size_t(m->load[d]) + 8);
+        if (!b) { rc[d] = AVR_ERR_HIP; err[d] = avr_last_error(); return; }
+        m->sub[d] = b;
+        for (size_t j = 0; j < mine[d].size() && rc[d] >= 0; j++) {
+            const uint32_t i = mine[d][j];
+            const uint8_t *p = m->store.data() + m->off[i];
+            int r;
+            if (m->kind == AVR_KIND_CABAC)
+                r = avr_batch_add_slice_cabac(b, reinterpret_cast<const uint16_t *>(p), m->n_bins[i], m->states.data() + size_t(i) * m->n_states, m->n_states);
+            else if (m->kind == AVR_KIND_RANGE) r = avr_batch_add_slice_range(b, reinterpret_cast<const uint16_t *>(p), m->n_bins[i]);
+            else r = avr_batch_add_slice_codes(b, p, m->n_bins[i]);
+            if (r < 0) { rc[d] = r; err[d] = avr_last_error(); }
+            else m->local[i] = r;
+        }
+        if (rc[d] >= 0 && (rc[d] = avr_batch_run(b)) < 0) err[d] = avr_last_error();      // the error text is per thread: carry it over
+    };
+    std::vector<std::thread> threads;
+    for (size_t d = 1; d < nd; d++) threads.emplace_back(work, d);
+    work(0);
+    for (std::thread &t : threads) t.join();
+    for (size_t d = 0; d < nd; d++)
+        if (rc[d] < 0) return fail(rc[d], "device entry %zu (device %d): %s", d, m->devices[d], err[d].c_str());
+    m->ran = true;
+    return AVR_OK;
+}
+
+int avr_multi_get(avr_multi *m, size_t slice, const uint8_t **bytes, size_t *len, int *status) {
+    if (!m || !m->ran) return fail(AVR_ERR_INVALID, "batch has not run");
+    if (slice >= m->n_bins.size()) return fail(AVR_ERR_INVALID, "slice %zu out of range", slice);
+    return avr_batch_get(m->sub[size_t(m->place[slice])], size_t(m->local[slice]), bytes, len, status);
+}
+
+int avr_multi_placement(avr_multi *m, size_t slice) {
+    if (!m || !m->ran) return fail(AVR_ERR_INVALID, "batch has not run");
+    if (slice >= m->n_bins.size()) return fail(AVR_ERR_INVALID, "slice %zu out of range", slice);
+    return m->place[slice];
+}
+
+int avr_multi_load(avr_multi *m, uint64_t *bins_per_device) {
+    if (!m || !m->ran || !bins_per_device) return fail(AVR_ERR_INVALID, "batch has not run");
+    for (size_t d = 0; d < m->load.size(); d++) bins_per_device[d] = m->load[d];
     return AVR_OK;
 }
 

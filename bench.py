@@ -156,6 +156,9 @@ def main():
                          "arithmetic-coding stage of K1p from (bin, state) codes resolved beforehand")
     ap.add_argument("--full-context-table", action="store_true",
                     help="keep the contexts as numbered by the stream (default: renumber the batch onto the contexts it uses)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank codes its own copy of the workload's slice count (default); strong: ONE batch of the "
+                         "workload's slice count is split over the ranks (contiguous ranges of near-equal bin totals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL; gloo lets several ranks rehearse on one GPU)")
@@ -164,7 +167,7 @@ def main():
     import torch
     import torch.distributed as dist
     import avrecode_ms_amd as avr
-    from avrecode_ms_amd.sharding import reduce_timing, shard_first_slice
+    from avrecode_ms_amd.sharding import balanced_ranges, reduce_timing, shard_first_slice
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,6 +189,17 @@ def main():
 
     n_slices = args.slices or DEFAULT_SLICES[args.workload]
     first = shard_first_slice(rank, n_slices)
+    batch_slices = n_slices
+    if args.scaling == "strong" and world > 1:
+        # One batch, sharded: every rank counts the bins of all slices on its own GPU (cheap next to generating them; same
+        # counts on every rank, so the same plan with nothing exchanged) and takes one contiguous range of the split.
+        import ctypes
+        cfg_all = avr.synth_config(args.workload, 1000, 0)
+        nb_all = torch.zeros(n_slices, dtype=torch.int32, device=dev)
+        avr._check(avr.lib().avr_synth_count_device(local_rank, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                                           ctypes.byref(cfg_all), kind, n_slices, nb_all.data_ptr()))
+        bounds = balanced_ranges(nb_all.cpu().numpy(), world)
+        first, n_slices = bounds[rank], bounds[rank + 1] - bounds[rank]
     w = avr.DeviceWorkload.synth(args.workload, n_slices, kind, local_rank, 1000, first)
     declared_states = w.n_states
 
@@ -258,10 +272,11 @@ def main():
             "value": total_bytes / t_max, "unit": "bytes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / max(args.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "u32" if kind == avr.KIND_CABAC else "u64", "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[args.workload], "kernel": "K1 cabac_encode" if kind == avr.KIND_CABAC else "K2 range_encode",
-                       "slices_per_gpu": n_slices, "bins_per_gpu": w.total_bins, "h264_bytes_per_gpu": out_bytes,
+                       "slices_per_gpu": n_slices, "batch_slices": batch_slices if args.scaling == "strong" else n_slices * world,
+                       "bins_per_gpu": w.total_bins, "h264_bytes_per_gpu": out_bytes,
                        "n_states": w.n_states, "n_states_declared": declared_states,
                        "layout": "slice-major" if path == "chunked" else "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -127,6 +127,25 @@ int avr_batch_get_states(avr_batch *b, size_t slice, const uint8_t **states, siz
 /* milliseconds of the last run: [0] H2D, [1] pack kernel, [2] encode kernel, [3] D2H */
 int avr_batch_timings(avr_batch *b, float ms[4]);
 
+/* ------------------------------------------------------------------ one batch over several GPUs
+ * Slices are independent (one coder object each in the reference, recode.cpp:1270, :1525), so a batch shards
+ * with no exchange between devices: avr_multi_run sorts the slices by bin count, hands them out longest first to
+ * the device with the least work so far (greedy LPT), runs one avr_batch per device from a host thread of its
+ * own (own stream, own pinned staging) and the getters return results by the caller's slice index.  `devices`
+ * may name a device more than once (it then gets that many independent sub-batches).  Same record formats,
+ * same rules (one kind per batch, one n_states) and same errors as the single-device batch. */
+typedef struct avr_multi avr_multi;
+avr_multi *avr_multi_create(const int *devices, size_t n_devices, size_t max_slices, size_t max_bins);
+void       avr_multi_destroy(avr_multi *m);
+int avr_multi_add_slice_cabac(avr_multi *m, const uint16_t *recs, size_t n, const uint8_t *init_states, size_t n_states);
+int avr_multi_add_slice_range(avr_multi *m, const uint16_t *recs, size_t n);
+int avr_multi_add_slice_codes(avr_multi *m, const uint8_t *codes, size_t n);
+int avr_multi_run(avr_multi *m);
+int avr_multi_get(avr_multi *m, size_t slice, const uint8_t **bytes, size_t *len, int *status);
+/* which entry of `devices` coded the slice, and the bins each entry was given (n_devices values): for tests and reports */
+int avr_multi_placement(avr_multi *m, size_t slice);
+int avr_multi_load(avr_multi *m, uint64_t *bins_per_device);
+
 /* ------------------------------------------------------------------ device-resident API
  * All pointers below are DEVICE pointers on `device`; `stream` is a hipStream_t (NULL = the
  * null stream).  Calls only enqueue work.  These are what the batch API is made of and what

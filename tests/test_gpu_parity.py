@@ -232,3 +232,32 @@ def test_full_size_properties(avr, oracle, workload, n_slices):
     # the "H.264 bytes" of the metric are the coded bytes; bins per bit stays in the realistic band
     total = sum(len(x) for x in got)
     assert 0.9 < w.total_bins / (8 * total) < 1.8
+
+
+def test_one_batch_over_several_devices(avr, oracle):
+    """avr_multi_*: one batch sharded by greedy LPT over a device list (here the same GPU named three times: three
+    sub-batches, each with its own host thread, stream and staging), results gathered by slice index."""
+    rng = np.random.default_rng(12)
+    slices = [oracle_lib.random_cabac_stream(rng, int(rng.lognormal(7.5, 1.0)), 120, terminate=bool(i % 4)) for i in range(90)]
+    want = [oracle.cabac_encode(r, s) for r, s in slices]
+    with avr.MultiBatch([0, 0, 0], len(slices), sum(len(r) for r, _ in slices) + 8) as m:
+        for r, s in slices:
+            m.add_slice_cabac(r, s)
+        m.run()
+        for i in range(len(slices)):
+            assert m.get(i) == (want[i][0], 0), f"slice {i}"
+        load = m.load()
+        owners = [m.placement(i) for i in range(len(slices))]
+    total = sum(len(r) for r, _ in slices)
+    assert sum(load) == total and set(owners) == {0, 1, 2}
+    assert max(load) - min(load) <= max(len(r) for r, _ in slices)       # LPT: no device is ahead by more than one slice
+    from avrecode_ms_amd.sharding import lpt_assign
+    assert owners == lpt_assign([len(r) for r, _ in slices], 3)           # the same plan bench.py's helper computes
+    # range records (the compress direction) through the same sharding
+    rr = [oracle_lib.random_range_stream(rng, int(rng.integers(0, 3000))) for _ in range(40)]
+    with avr.MultiBatch([0, 0], len(rr), sum(len(r) for r in rr) + 8) as m:
+        for r in rr:
+            m.add_slice_range(r)
+        m.run()
+        for i, r in enumerate(rr):
+            assert m.get(i) == oracle.range_encode(r), f"range slice {i}"

@@ -53,3 +53,63 @@ def test_two_rank_gloo_sharding(tmp_path, avr):
     assert res["mine"] == nb[:6].tolist()                 # rank 0 owns slices 0..5, rank 1 owns 6..11
     assert res["units"] == int(nb.sum())                  # sum over ranks == the unsharded workload
     assert res["t_max"] == 2.0                            # max over ranks of the per-rank time
+
+
+STRONG_WORKER = textwrap.dedent("""
+    import ctypes, json, os, sys
+    import numpy as np
+    import torch, torch.distributed as dist
+    sys.path.insert(0, {root!r})
+    import avrecode_ms_amd as avr
+    from avrecode_ms_amd.sharding import balanced_ranges, lpt_assign
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    total = 400
+    cfg = avr.synth_config(3, 4, 0)                       # config 3: log-normal slice lengths, the imbalance case
+    nb = np.zeros(total, dtype=np.uint32)
+    assert avr.lib().avr_synth_count_host(ctypes.byref(cfg), 0, total, nb.ctypes.data) == 0
+    bounds = balanced_ranges(nb, world)                   # every rank computes the same plan from the same counts
+    lo, hi = bounds[rank], bounds[rank + 1]
+    owner = lpt_assign(nb, world)
+    mine_lpt = [i for i in range(total) if owner[i] == rank]
+    out = [None] * world
+    dist.all_gather_object(out, dict(rank=rank, lo=lo, hi=hi, bins=int(nb[lo:hi].sum()), lpt=mine_lpt,
+                                     lpt_bins=int(nb[mine_lpt].sum()), all_bins=int(nb.sum())))
+    if rank == 0:
+        print(json.dumps(out))
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_strong_split_covers_everything_and_balances(tmp_path, avr):
+    """Strong scaling of one batch (BASELINE.json configs[3]: NAL batches sharded across the GPUs of a node): the union of
+    the ranks' shards is the unsharded slice set, and the ranks' bin totals are within 2 % of each other -- for the
+    contiguous split bench.py --scaling strong uses and for the LPT plan of avr_multi_run."""
+    import json
+    script = tmp_path / "strong.py"
+    script.write_text(STRONG_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29618", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("[")][-1])
+    assert [r["rank"] for r in res] == [0, 1]
+    assert res[0]["lo"] == 0 and res[0]["hi"] == res[1]["lo"] and res[1]["hi"] == 400          # contiguous, disjoint, complete
+    total = res[0]["all_bins"]
+    assert res[0]["bins"] + res[1]["bins"] == total
+    assert abs(res[0]["bins"] - res[1]["bins"]) <= 0.02 * total
+    assert sorted(res[0]["lpt"] + res[1]["lpt"]) == list(range(400))                            # LPT: a partition too
+    assert abs(res[0]["lpt_bins"] - res[1]["lpt_bins"]) <= 0.02 * total
+
+
+def test_lpt_and_balanced_ranges_small_cases():
+    from avrecode_ms_amd.sharding import balanced_ranges, lpt_assign
+    assert lpt_assign([5, 1, 1, 1, 1, 1], 2) == [0, 1, 1, 1, 1, 1]
+    assert lpt_assign([], 3) == []
+    assert balanced_ranges([1, 1, 1, 1], 2) == [0, 2, 4]
+    assert balanced_ranges([10, 1, 1], 2) == [0, 1, 3]
+    assert balanced_ranges([], 2) == [0, 0, 0]
+    b = balanced_ranges([3] * 10, 4)
+    assert b[0] == 0 and b[-1] == 10 and all(x <= y for x, y in zip(b, b[1:]))
