@@ -111,6 +111,7 @@ class cabac_bin_decoder {
         return 0;
     }
     static const CabacTables &tables() { static const CabacTables t = make_cabac_tables(); return t; }
+    size_t bit_position() const { return pos_; }         // bits read so far: the 9 of the initialisation + one per renormalisation shift
 
   private:
     uint32_t read_bit() {

@@ -46,6 +46,11 @@ struct stream_decoder {
     virtual ~stream_decoder() {}
     // decode everything, pulling bytes through read_packet(opaque, buffer, size) and calling h
     virtual void decode_video(hooks *h, int (*read_packet)(void *, uint8_t *, int), void *opaque) = 0;
+    // Asked by the compressor inside init_decoder, about the payload being offered: will the decoder get through it?
+    // libavcodec always does; the build's own syntax parser (avr_h264.h) covers a subset of H.264 and answers by
+    // trying.  "No" makes the compressor treat the slice like one whose payload it cannot find (skip_coded block,
+    // the bytes stay literal): the container stays lossless whatever the parser can or cannot do.
+    virtual bool payload_decodes() { return true; }
 };
 
 inline void gpu_check(int rc) { if (rc < 0) throw std::runtime_error(std::string("avr: ") + avr_last_error()); }
@@ -122,6 +127,7 @@ class compressor {                                       // recode.cpp:1109-1316
     compressor(const std::string &original_bytes, int device = 0) : original_(original_bytes), device_(device) {}
 
     std::string run(stream_decoder *d) {                 // :1122-1132
+        decoder_ = d;
         hooks h = hook_adapter<compressor>::make(this);
         d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<compressor *>(o)->read_packet(buf, size); }, this);
         cabac_contexts.clear();
@@ -193,7 +199,7 @@ class compressor {                                       // recode.cpp:1109-1316
     int find_next_coded_block_and_emit_literal(const uint8_t *buf, int size) {
         const size_t window_begin = size_t(prev_coded_block_end_), window_end = size_t(read_offset_);
         size_t where = std::string::npos;
-        if (size >= SURROGATE_MARKER_BYTES) {
+        if (size >= SURROGATE_MARKER_BYTES && (!decoder_ || decoder_->payload_decodes())) {
             const void *hit = memmem(original_.data() + window_begin, window_end - window_begin, buf, size_t(size));
             if (hit) where = size_t(static_cast<const char *>(hit) - original_.data());
         }
@@ -246,6 +252,7 @@ class compressor {                                       // recode.cpp:1109-1316
     int device_;
     int read_offset_ = 0, prev_coded_block_end_ = 0;
     context_ids contexts_;                               // one numbering of the state addresses for the whole file
+    stream_decoder *decoder_ = nullptr;
     h264_model model_;
     Recoded out_;
     std::vector<pending> pending_;
