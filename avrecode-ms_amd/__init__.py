@@ -61,6 +61,31 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+RECODE_PATH = os.path.join(_HERE, "recode")
+_HOST = os.path.join(_CSRC, "host")
+
+
+def build_recode(force: bool = False, verbose: bool = False) -> str:
+    """Compile the `recode` command line (csrc/host/recode_main.cpp: the reference's CLI, recode.cpp:1642-1677, on this
+    build's H.264 syntax parser and GPU batches) next to libavrecode_hip.so, which it links."""
+    deps = [os.path.join(_HOST, f) for f in ("recode_main.cpp", "avr_h264.h", "avr_h264_tables.h", "avr_recode.h", "avr_host.h", "avr_model.h")]
+    deps += [HEADER_PATH, LIB_PATH]
+    if not force and os.path.exists(RECODE_PATH) and all(os.path.getmtime(RECODE_PATH) >= os.path.getmtime(d) for d in deps):
+        return RECODE_PATH
+    cxx = shutil.which("g++") or shutil.which("hipcc")
+    if not cxx:
+        if os.path.exists(RECODE_PATH):
+            return RECODE_PATH
+        raise AvrError("no C++ compiler and no prebuilt recode binary")
+    cmd = [cxx, "-O2", "-std=c++17", "-I" + _CSRC, "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", RECODE_PATH + ".tmp",
+           os.path.join(_HOST, "recode_main.cpp"), "-L" + _HERE, "-lavrecode_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(RECODE_PATH + ".tmp", RECODE_PATH)
+    return RECODE_PATH
+
+
 class ChunkPlan(ctypes.Structure):
     """avr_chunk_plan: device arrays of the intra-slice parallel path (include/avrecode_ms_amd.h)."""
     _fields_ = [("res_off", c_void_p), ("chunk_base", c_void_p), ("chunk_slice", c_void_p), ("blk_base", c_void_p),
@@ -336,6 +361,6 @@ class MultiBatch:
 
 from .device import DeviceWorkload, encode_tiles, plan_tiles, synth_config  # noqa: E402  (torch-backed helpers)
 
-__all__ = ["AvrError", "Batch", "MultiBatch", "DeviceWorkload", "KIND_CABAC", "KIND_RANGE", "SEL_BYPASS", "SEL_TERMINATE",
+__all__ = ["AvrError", "Batch", "MultiBatch", "build_recode", "RECODE_PATH", "DeviceWorkload", "KIND_CABAC", "KIND_RANGE", "SEL_BYPASS", "SEL_TERMINATE",
            "build_native", "cabac_tables", "device_count", "drop_stop_byte", "encode_tiles", "lib",
            "make_cabac_records", "make_range_records", "plan_tiles", "synth_config", "tail_patch"]
