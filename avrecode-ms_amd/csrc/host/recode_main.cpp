@@ -63,8 +63,8 @@ void dump_stream_info(const std::string &path, const std::string &bytes, int ind
             const uint32_t timescale = h264::be32(&d[p]);
             const uint64_t dur = version ? (uint64_t(h264::be32(&d[p + 4])) << 32 | h264::be32(&d[p + 8])) : h264::be32(&d[p + 4]);
             if (timescale) duration = double(dur) / timescale;
-        } else if (!memcmp(&d[i], avc1, 4) && !width) {
-            width = unsigned(d[i + 4 + 24]) << 8 | d[i + 4 + 25];
+        } else if (!memcmp(&d[i], avc1, 4) && !width && i + 4 + 78 + 8 <= d.size() && !memcmp(&d[i + 4 + 78 + 4], "avcC", 4)) {
+            width = unsigned(d[i + 4 + 24]) << 8 | d[i + 4 + 25];       // the sample entry (not the brand of the same name in ftyp)
             height = unsigned(d[i + 4 + 26]) << 8 | d[i + 4 + 27];
         } else if (!memcmp(&d[i], stsz, 4) && !samples && width) samples = h264::be32(&d[i + 12]);
     }
