@@ -137,11 +137,6 @@ struct avr_batch {
     DevBuf<uint32_t> d_chunk_base, d_chunk_slice, d_blk_base, d_blk_slice;
     DevBuf<uint8_t> d_workspace;
     int last_path = 0;                      // 0 = one lane per slice, 1 = chunked
-    // dense context ids: the batch is renumbered onto the contexts it uses
-    DevBuf<uint32_t> d_bitmap;
-    DevBuf<uint16_t> d_table, d_index;
-    DevBuf<uint8_t> d_states_dense, d_final_dense;
-    size_t n_dense = 0;                     // 0: not renumbered
 };
 
 extern "C" {
@@ -194,7 +189,6 @@ void avr_batch_destroy(avr_batch *b) {
     b->d_out.release(); b->d_dense.release();
     b->d_res_off.release(); b->d_dig_off.release(); b->d_chunk_base.release(); b->d_chunk_slice.release();
     b->d_blk_base.release(); b->d_blk_slice.release(); b->d_workspace.release();
-    b->d_bitmap.release(); b->d_table.release(); b->d_index.release(); b->d_states_dense.release(); b->d_final_dense.release();
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -383,36 +377,11 @@ int avr_batch_run(avr_batch *b) {
     bool chunked = cabac && n <= 32768 && b->total_bins / n >= 8192;
     if (const char *force = getenv("AVR_K1_PATH")) chunked = cabac && strcmp(force, "chunked") == 0;
     b->last_path = chunked;
-    // Renumber the batch onto the contexts it uses (K1 keeps 64 x n_states state bytes in LDS per wave).
-    // The intra-slice parallel kernels do this themselves, inside their histogram pass.
+    // Both K1 paths renumber the batch onto the contexts it uses themselves (the intra-slice parallel kernels inside
+    // their census pass, the one-lane-per-slice kernel through launch_cabac_encode): records and states go in as they are.
     const uint8_t *k_states = b->d_states.p;
     uint8_t *k_final = b->d_final.p;
-    size_t k_ns = ns;
-    b->n_dense = 0;
-    if (cabac && !chunked && ns > 1 && !getenv("AVR_NO_DENSE")) {
-        if ((rc = b->d_bitmap.reserve(32)) || (rc = b->d_table.reserve(1024)) || (rc = b->d_index.reserve(1024))) return rc;
-        AVR_HIP(hipMemsetAsync(b->d_bitmap.p, 0, 32 * sizeof(uint32_t), s));
-        AVR_HIP(avr::launch_context_census(s, b->d_recs.p, total_recs, b->d_bitmap.p));
-        uint32_t bitmap[32];
-        AVR_HIP(hipMemcpyAsync(bitmap, b->d_bitmap.p, sizeof bitmap, hipMemcpyDeviceToHost, s));
-        AVR_HIP(hipStreamSynchronize(s));
-        std::vector<uint16_t> table(1024, 1023), index;       // unused / out-of-range selectors map to an id no slice has
-        for (uint32_t sel = 0; sel < ns; sel++)
-            if (bitmap[sel >> 5] >> (sel & 31) & 1) { table[sel] = uint16_t(index.size()); index.push_back(uint16_t(sel)); }
-        if (index.size() < ns && index.size() < 1023) {
-            const size_t nd = std::max<size_t>(index.size(), 1);
-            if ((rc = b->d_states_dense.reserve(n * nd)) || (rc = b->d_final_dense.reserve(n * nd))) return rc;
-            AVR_HIP(hipMemcpyAsync(b->d_table.p, table.data(), 1024 * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-            if (!index.empty()) AVR_HIP(hipMemcpyAsync(b->d_index.p, index.data(), index.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-            AVR_HIP(hipStreamSynchronize(s));
-            AVR_HIP(avr::launch_context_remap(s, b->d_recs.p, total_recs, b->d_table.p));
-            AVR_HIP(hipMemsetAsync(b->d_states_dense.p, 0, n * nd, s));
-            AVR_HIP(avr::launch_states_permute(s, b->d_states.p, uint32_t(ns), b->d_states_dense.p, uint32_t(nd), b->d_index.p,
-                                               uint32_t(index.size()), n, 0));
-            k_states = b->d_states_dense.p; k_final = b->d_final_dense.p; k_ns = nd;
-            b->n_dense = index.size() ? index.size() : size_t(-1);
-        }
-    }
+    const size_t k_ns = ns;
     if (chunked) {
         std::vector<uint64_t> res_off(n + 1, 0), dig_off(n + 1, 0);
         std::vector<uint32_t> chunk_base(n + 1, 0), blk_base(n + 1, 0), chunk_slice, blk_slice;
@@ -456,12 +425,6 @@ int avr_batch_run(avr_batch *b) {
         else
             AVR_HIP(avr::launch_range_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_out.p,
                                              b->d_out_off.p, b->d_out_len.p, b->d_status.p));
-    }
-    if (b->n_dense) {        // final states back in the caller's numbering; untouched contexts keep their initial state
-        AVR_HIP(hipMemcpyAsync(b->d_final.p, b->d_states.p, n * ns, hipMemcpyDeviceToDevice, s));
-        if (b->n_dense != size_t(-1))
-            AVR_HIP(avr::launch_states_permute(s, b->d_final_dense.p, uint32_t(k_ns), b->d_final.p, uint32_t(ns), b->d_index.p,
-                                               uint32_t(b->n_dense), n, 1));
     }
     return fetch_output(b, out_off, n32);
 }

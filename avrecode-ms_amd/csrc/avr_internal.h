@@ -21,7 +21,9 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
                                const uint8_t *init_states, uint32_t n_states, uint8_t *out,
                                const uint64_t *out_off, uint32_t *out_len, int32_t *status,
-                               uint8_t *final_states, int32_t want_status = AVR_SLICE_OK);
+                               uint8_t *final_states, int32_t want_status = AVR_SLICE_OK, bool dense = true);
+// used (1024 bits) -> table[caller's context number] = dense id (0xffff: unused), index[dense id] = caller's number, *n_dense
+hipError_t launch_densemap(hipStream_t s, const uint32_t *used, uint16_t *table, uint16_t *index, uint32_t *n_dense);
 hipError_t launch_range_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
                                uint8_t *out, const uint64_t *out_off, uint32_t *out_len,

@@ -945,6 +945,11 @@ static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, c
     return hipGetLastError();
 }
 
+hipError_t launch_densemap(hipStream_t s, const uint32_t *used, uint16_t *table, uint16_t *index, uint32_t *n_dense) {
+    hipLaunchKernelGGL(k_k1p_densemap, dim3(1), dim3(1024), 0, s, used, table, index, n_dense);
+    return hipGetLastError();
+}
+
 hipError_t launch_cabac_encode_codes(hipStream_t s, const uint8_t *codes, const uint64_t *res_off, const uint32_t *n_bins,
                                      const uint32_t *order, uint32_t n_slices, uint8_t *out, const uint64_t *out_off,
                                      uint32_t *out_len, int32_t *status, int32_t want_status) {

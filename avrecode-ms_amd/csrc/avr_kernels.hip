@@ -20,6 +20,7 @@
 //                       never conflict across lanes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "avr_coder.h"
 #include "avr_internal.h"
@@ -29,7 +30,6 @@
 namespace avr {
 
 static __device__ const CabacTables d_tables = make_cabac_tables();
-constexpr uint32_t kTabDwords = 2 * 136;               // packed table: 128 states + 8 pseudo-states
 
 // ------------------------------------------------------------------ record fetch
 
@@ -55,66 +55,72 @@ struct ChunkSource {
 // One CABAC bin (cabac_code.h:33-67 on arithmetic_code.h:106-126), written branch-free up to
 // the renormalisation: every lane does the same LDS read / table read / LDS write whatever
 // kind of bin it holds, so a wave never splits on context-vs-bypass.
-//   * a context bin reads and writes its state byte; any other bin reads and writes the
-//     lane's scratch byte (row `n_rows` of the state area);
-//   * terminate and the no-op record are table rows of their own (pseudo-states 130, 132:
-//     LPS range 2 resp. 0 in every range quarter, valMPS 0), bypass (128) overrides the
-//     table value with range/2.
-// Returns true when the bin was put_terminate(1): the caller stops and runs finish().
+//   * where a bin's state byte lives comes from one look-up, sel_off[selector]: contexts have their
+//     byte in the lane's column of the state rows; bypass, terminate and everything else (padding,
+//     selectors that are no context of the batch) go to pseudo contexts whose pseudo states never move;
+//   * the pseudo states are table rows of their own: 128 bypass (flag in .y: the coded range is
+//     range / 2), 130 terminate (LPS range 2 in every range quarter, valMPS 0), 132 no-op (LPS range 0,
+//     and a flag in .y that forces symbol 0, so such a record changes nothing whatever its bin).
+// Returns nothing; put_terminate(1) is found by the caller from the record value.
 struct CabacLane {
     CabacEncoder e;
-    uint32_t lane4;         // 4 * lane: this lane's column in the state dwords
-    uint32_t n_states;
-    uint32_t scratch;       // byte offset of the lane's scratch dword
 
-    __device__ __forceinline__ void bin(uint32_t rec, const uint2 *tab, uint8_t *st8) {
-        const uint32_t sel = (rec >> 1) & 0x7ffu;
-        const bool is_ctx = sel < n_states;
-        // state byte of (context, lane): dword (sel >> 2, lane), byte sel & 3
-        const uint32_t saddr = is_ctx ? (((sel >> 2) << 8) + (sel & 3) + lane4) : scratch;
-        uint32_t s_mem = st8[saddr];
+    __device__ __forceinline__ void bin(uint32_t rec, uint32_t off, const uint2 *tab, uint8_t *st_lane) {
+        uint8_t *sp = st_lane + off;                             // state byte of (context, lane): dword (k >> 2, lane), byte k & 3
+        uint32_t s = *sp;
         // The empty asm statements pin the two LDS reads where they are written: without them
         // hipcc sinks each read into a branch on the bin kind (it is only "needed" on one side of
         // a select), which splits the wave and exposes the full LDS latency behind every branch.
-        asm volatile("" : "+v"(s_mem));
-        // 1024 -> 128, 1025 -> 130, 1026 and anything that is no context of the slice -> 132 (| bin: rows 132 and 133 are
-        // both "LPS range 0", and with valMPS = bin the symbol is 0, so such a record changes nothing whatever its bin)
-        const uint32_t t = min(2 * sel - 1920, 132u);
-        const uint32_t s = is_ctx ? (s_mem & 127u) : (t | ((t >> 2) == 33u ? rec & 1u : 0u));
+        asm volatile("" : "+v"(s));
         uint2 ent = tab[s];
         asm volatile("" : "+v"(ent.x), "+v"(ent.y));
         // normalize = floor(log2(range / 0x100)) (cabac_code.h:37,59,70-79); range != 0 here
         const int norm = 23 - __builtin_clz(e.range);
         const uint32_t q = (e.range >> (norm + 6)) & 3;          // (range_approx & 0x180) >> 7, :39-40
         const uint32_t r_tab = ((ent.x >> (q * 8)) & 0xffu) << norm;              // :40-41, :60
-        // bypass (:53): its table row is 0 and the top half of ent.y is all ones, so this is an OR, not a branch
+        // bypass (:53): its table row is 0 and the top bit of ent.y is set, so this is an OR, not a branch
         const uint32_t r1 = r_tab | ((e.range >> 1) & uint32_t(int32_t(ent.y) >> 31));
-        const uint32_t sym = (rec ^ s) & 1;                      // :34 (pseudo-states have valMPS 0)
+        const uint32_t sym = (rec ^ s) & 1 & ~(ent.y >> 30);     // :34 (pseudo-states have valMPS 0; the no-op row forces 0)
         const uint32_t r0 = e.range - r1;                        // arithmetic_code.h:107-114
         e.low += sym ? r0 : 0u;
         e.range = sym ? r1 : r0;
-        st8[saddr] = uint8_t(ent.y >> (8 * sym));                // cabac_code.h:43-47
+        *sp = uint8_t(ent.y >> (8 * sym));                       // cabac_code.h:43-47
         if (e.range < 0x200u) e.emit_digit();                    // arithmetic_code.h:115-122 (one digit)
     }
 };
 
+constexpr uint32_t kK1Waves = 4;                                 // waves per workgroup (fewer when the state rows are large): they share the two tables
+
+// table / index: the dense renumbering of the batch's contexts (k_k1p_densemap), or null: contexts as the caller
+// numbers them.  n_rows: contexts the kernel keeps states for (dense count, or n_states); init_states / final_states
+// rows are n_states wide, in the caller's numbering.
 template <bool TILED>
-__global__ __launch_bounds__(64) void k_cabac_encode(
+__global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
-    uint32_t n_slices, const uint8_t *init_states, uint32_t n_states,
+    uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const uint16_t *table, const uint16_t *index, uint32_t n_rows,
     uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
     uint8_t *final_states, int32_t want_status) {
-    extern __shared__ uint32_t lds[];
-    uint2 *tab = reinterpret_cast<uint2 *>(lds);                 // 128 states + pseudo-states 128..135
-    uint32_t *st32 = lds + kTabDwords;                           // state dwords
-    uint8_t *st8 = reinterpret_cast<uint8_t *>(st32);
+    extern __shared__ uint32_t lds[];                            // per wave: state dwords [(n_rows + 3 + 3) / 4][64]
+    __shared__ uint2 tab[136];                                   // 128 states + pseudo-states 128..135
+    __shared__ uint32_t sel_off[2048];                           // selector -> byte offset of its state in the lane's column (up to 256 rows of 256 bytes, + 3)
 
-    const uint32_t lane = threadIdx.x;
-    const uint32_t g = blockIdx.x * 64 + lane;
-    for (uint32_t i = lane; i < 128; i += 64)
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rows4 = (n_rows + 3 + 3) >> 2;                // contexts, then three pseudo contexts
+    uint32_t *st32 = lds + wv * rows4 * 64;
+    uint8_t *st_lane = reinterpret_cast<uint8_t *>(st32) + lane * 4;
+    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x)
         tab[i] = make_uint2(d_tables.packed[i][0], d_tables.packed[i][1]);
-    if (lane < 8)                                                // 128: bypass (flagged in .y), 130: terminate (LPS range 2), others 0
-        tab[128 + lane] = make_uint2(lane == 2 ? 0x02020202u : 0u, lane == 0 ? 0xffff0000u : 0u);
+    if (threadIdx.x < 8) {                                       // 128: bypass, 130: terminate (LPS range 2), 132: no-op; each is its own successor
+        const uint32_t st = 128 + threadIdx.x;
+        tab[st] = make_uint2(threadIdx.x == 2 ? 0x02020202u : 0u, (threadIdx.x == 0 ? 0x80000000u : threadIdx.x == 4 ? 0x40000000u : 0u) | st | st << 8);
+    }
+    for (uint32_t sel = threadIdx.x; sel < 2048; sel += blockDim.x) {
+        uint32_t k;
+        if (sel < 1024) { const uint32_t d = table ? uint32_t(table[sel]) : (sel < n_states ? sel : 0xffffu); k = d < n_rows ? d : n_rows + 2; }
+        else k = sel == AVR_SEL_BYPASS ? n_rows : sel == AVR_SEL_TERMINATE ? n_rows + 1 : n_rows + 2;
+        sel_off[sel] = ((k >> 2) << 8) + (k & 3);
+    }
 
     const bool in_range = g < n_slices;
     const uint32_t slice = in_range ? (order ? order[g] : g) : 0;
@@ -124,16 +130,19 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
     const bool active = in_range && st == want_status;
     if (active) st = AVR_SLICE_OK;
     const uint32_t nb = active ? n_bins[slice] : 0;
-    const uint32_t ns4 = (n_states + 3) >> 2;
 
-    // states: global (n_states bytes per slice) -> LDS column of this lane
-    if (active) {
+    // states: global (n_states bytes per slice, caller's numbering) -> LDS column of this lane
+    {
         const uint8_t *src = init_states + size_t(slice) * n_states;
-        for (uint32_t k = 0; k < ns4; k++) {
+        for (uint32_t k4 = 0; k4 < rows4; k4++) {
             uint32_t v = 0;
-            for (uint32_t b = 0; b < 4; b++)
-                if (4 * k + b < n_states) v |= uint32_t(src[4 * k + b]) << (8 * b);
-            st32[k * 64 + lane] = v;
+            for (uint32_t b = 0; b < 4; b++) {
+                const uint32_t k = 4 * k4 + b;
+                uint32_t sv = k == n_rows ? 128u : k == n_rows + 1 ? 130u : 132u;     // the pseudo contexts (and the padding of the last dword)
+                if (k < n_rows && active) sv = src[index ? uint32_t(index[k]) : k];
+                v |= sv << (8 * b);
+            }
+            st32[k4 * 64 + lane] = v;
         }
     }
     __syncthreads();
@@ -142,11 +151,8 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
     const uint64_t o0 = in_range ? out_off[slice] : 0;
     const uint32_t cap = in_range ? uint32_t(out_off[slice + 1] - o0) : 0;
     L.e.init(0x7F800000u, out + o0, cap);                        // cabac_code.h:30
-    L.lane4 = lane * 4;
-    L.n_states = n_states;
-    L.scratch = ns4 * 256 + lane * 4;                            // one dword row past the states
 
-    const ChunkSource<TILED> src(recs, off, g, slice);
+    const ChunkSource<TILED> src(recs, off, in_range ? g : 0, slice);
     const uint32_t n_chunks = (nb + 7) >> 3;
     const uint4 nop4 = make_uint4(AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2);
     uint4 cur = n_chunks > 0 ? src.load(0) : nop4;
@@ -158,15 +164,15 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
     constexpr uint32_t kTerm1 = (AVR_SEL_TERMINATE << 1) | 1;
     for (uint32_t c = 0; c < n_chunks && term_at == 0xffffffffu; c++) {
         const uint4 nx2 = (c + 2 < n_chunks) ? src.load(c + 2) : nop4;
-        uint32_t w0 = cur.x, w1 = cur.y, w2 = cur.z, w3 = cur.w;
-#pragma unroll 1
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t d = w0;
-            w0 = w1; w1 = w2; w2 = w3;
-            const uint32_t i = c * 8 + 2 * k;
-            L.bin(d & 0xffffu, tab, st8);
-            L.bin(d >> 16, tab, st8);
-            const uint32_t t0 = (d & 0xffffu) == kTerm1 ? i : (d >> 16) == kTerm1 ? i + 1 : 0xffffffffu;
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t offs[8];                                        // where the eight bins' states live: independent of the states, read ahead
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) offs[k] = sel_off[((w[k >> 1] >> ((k & 1) * 16)) >> 1) & 0x7ffu];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t rec = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+            L.bin(rec, offs[k], tab, st_lane);
+            const uint32_t t0 = rec == kTerm1 ? c * 8 + k : 0xffffffffu;
             term_at = term_at < t0 ? term_at : t0;
         }
         cur = nx1;
@@ -181,14 +187,55 @@ __global__ __launch_bounds__(64) void k_cabac_encode(
         }
         if (active) { out_len[slice] = L.e.w.n; status[slice] = st; }
         else if (want_status == AVR_SLICE_OK) out_len[slice] = 0;
-        if (final_states && active) {
+        if (final_states && active) {                            // final_states starts out as a copy of init_states when a renumbering is in use
             uint8_t *dst = final_states + size_t(slice) * n_states;
-            for (uint32_t k = 0; k < ns4; k++) {
-                const uint32_t v = st32[k * 64 + lane];
-                for (uint32_t b = 0; b < 4; b++)
-                    if (4 * k + b < n_states) dst[4 * k + b] = uint8_t(v >> (8 * b));
-            }
+            const uint8_t *col = reinterpret_cast<const uint8_t *>(st32) + lane * 4;
+            for (uint32_t k = 0; k < n_rows; k++) dst[index ? uint32_t(index[k]) : k] = col[((k >> 2) << 8) + (k & 3)];
         }
+    }
+}
+
+// Which contexts the records of a tile / a slice use (one bit per selector < 1024): the census behind the dense
+// renumbering, for the one-lane-per-slice kernel.  One workgroup per 64 slices; plain LDS flag stores, then the
+// global words are only touched while a bit is still missing (see k_k1p_census).
+template <bool TILED>
+__global__ __launch_bounds__(256) void k_k1_census(const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
+                                                   uint32_t n_slices, uint32_t *used) {
+    __shared__ uint8_t flag[1024];
+    __shared__ uint32_t bm[32];
+    reinterpret_cast<uint32_t *>(flag)[threadIdx.x] = 0;
+    if (threadIdx.x < 32) bm[threadIdx.x] = 0;
+    __syncthreads();
+    auto take = [&](const uint4 &v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t sel = ((w[j >> 1] >> ((j & 1) * 16)) >> 1) & 0x7ffu;
+            if (sel < 1024) flag[sel] = 1;
+        }
+    };
+    if (TILED) {                                                 // the tile is one contiguous run of 16-byte chunks
+        const uint4 *p = reinterpret_cast<const uint4 *>(recs) + off[blockIdx.x];
+        const uint64_t n = off[blockIdx.x + 1] - off[blockIdx.x];
+        for (uint64_t i = threadIdx.x; i < n; i += 256) take(p[i]);
+    } else {
+        for (uint32_t l = 0; l < 64; l++) {
+            const uint32_t g = blockIdx.x * 64 + l;
+            if (g >= n_slices) break;
+            const uint32_t slice = order ? order[g] : g;
+            const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(recs) + off[slice]);
+            const uint32_t n = (n_bins[slice] + 7) >> 3;
+            for (uint32_t i = threadIdx.x; i < n; i += 256) take(p[i]);
+        }
+    }
+    __syncthreads();
+    const uint32_t f = reinterpret_cast<const uint32_t *>(flag)[threadIdx.x];
+    const uint32_t nib = (f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u);
+    if (nib) atomicOr(&bm[threadIdx.x >> 3], nib << ((threadIdx.x & 7) * 4));
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const uint32_t mine = bm[threadIdx.x];
+        if (mine & ~__hip_atomic_load(&used[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&used[threadIdx.x], mine);
     }
 }
 
@@ -467,28 +514,54 @@ __global__ __launch_bounds__(64) void k_synth_slices(
 
 // ------------------------------------------------------------------ launchers
 
-static inline uint32_t cabac_lds_bytes(uint32_t n_states) {
-    const uint32_t rows = (n_states + 3) / 4;
-    return kTabDwords * 4 + 64 * 4 * (rows + 1);       // table + state rows + one scratch row
-}
-
+// The one-lane-per-slice kernel keeps 64 x (contexts) state bytes in LDS per wave, so it renumbers the batch onto the
+// contexts its records use (census -> k_k1p_densemap -> one 4-byte read-back to size the launch), applied to the
+// records as they are loaded (sel_off): nothing is rewritten, init_states / final_states stay in the caller's numbering.
+// dense = false (and every hand-over from K1p, want_status != OK): the caller's numbering as it is.
 hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
                                const uint8_t *init_states, uint32_t n_states, uint8_t *out,
                                const uint64_t *out_off, uint32_t *out_len, int32_t *status,
-                               uint8_t *final_states, int32_t want_status) {
+                               uint8_t *final_states, int32_t want_status, bool dense) {
     if (n_slices == 0) return hipSuccess;
-    const uint32_t lds = cabac_lds_bytes(n_states);
-    const dim3 grid((n_slices + 63) / 64), block(64);
+    hipError_t err;
+    uint32_t n_rows = n_states;
+    uint8_t *scratch = nullptr;                                  // used[32] + n_dense | table[1024] | index[1024]
+    const uint16_t *table = nullptr, *index = nullptr;
+    if (dense && want_status == AVR_SLICE_OK && n_states > 8 && !getenv("AVR_NO_DENSE")) {
+        if ((err = hipMallocAsync(reinterpret_cast<void **>(&scratch), 256 + 4096, s)) != hipSuccess) return err;
+        uint32_t *used = reinterpret_cast<uint32_t *>(scratch);
+        uint16_t *t = reinterpret_cast<uint16_t *>(scratch + 256);
+        if ((err = hipMemsetAsync(used, 0, 256, s)) != hipSuccess) return err;
+        const dim3 cgrid((n_slices + 63) / 64);
+        if (tiled) hipLaunchKernelGGL(k_k1_census<true>, cgrid, dim3(256), 0, s, recs, off, n_bins, order, n_slices, used);
+        else hipLaunchKernelGGL(k_k1_census<false>, cgrid, dim3(256), 0, s, recs, off, n_bins, order, n_slices, used);
+        if ((err = launch_densemap(s, used, t, t + 1024, used + 32)) != hipSuccess) return err;
+        uint32_t nd = 0;
+        if ((err = hipMemcpyAsync(&nd, used + 32, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return err;
+        if ((err = hipStreamSynchronize(s)) != hipSuccess) return err;
+        // a selector >= n_states is not a context of the slice even if it occurs: the table only serves selectors < n_states
+        // (k_pack_tiles has flagged such records; the kernel sends them to the no-op row either way, see sel_off)
+        n_rows = nd < n_states ? nd : n_states;
+        table = t;
+        index = t + 1024;
+        if (final_states && (err = hipMemcpyAsync(final_states, init_states, size_t(n_slices) * n_states, hipMemcpyDeviceToDevice, s)) != hipSuccess)
+            return err;                                          // contexts without bins keep their state
+    }
+    const uint32_t per_wave = ((n_rows + 3 + 3) / 4) * 256;
+    const uint32_t waves = per_wave * kK1Waves <= 60 * 1024 ? kK1Waves : per_wave * 2 <= 60 * 1024 ? 2 : 1;
+    const uint32_t lds = waves * per_wave;
+    const dim3 grid((n_slices + 64 * waves - 1) / (64 * waves)), block(64 * waves);
     auto kern = tiled ? k_cabac_encode<true> : k_cabac_encode<false>;
-    if (lds > 64 * 1024) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (lds > 48 * 1024) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (err != hipSuccess) return err;
     }
-    hipLaunchKernelGGL(kern, grid, block, lds, s, recs, off, n_bins, order, n_slices, init_states,
-                       n_states, out, out_off, out_len, status, final_states, want_status);
-    return hipGetLastError();
+    hipLaunchKernelGGL(kern, grid, block, lds, s, recs, off, n_bins, order, n_slices, init_states, n_states, table, index, n_rows, out,
+                       out_off, out_len, status, final_states, want_status);
+    err = hipGetLastError();
+    if (scratch) { const hipError_t e2 = hipFreeAsync(scratch, s); if (err == hipSuccess) err = e2; }
+    return err;
 }
 
 hipError_t launch_range_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,

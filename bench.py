@@ -208,19 +208,12 @@ def main():
         path = "chunked" if (kind == avr.KIND_CABAC and n_slices <= 32768 and w.total_bins // max(n_slices, 1) >= 8192) else "serial"
     if kind != avr.KIND_CABAC:
         path = "serial"
-    # The step contains everything a batch needs.  The intra-slice parallel kernels renumber the batch onto the
-    # contexts it uses inside their own histogram pass (nothing happens outside the step).  The one-lane-per-slice
-    # kernel wants the dense numbering in its records: there the renumbering (census + in-place remap + state
-    # gather) runs before the first step and is timed on its own -- its time is ADDED to every step below.
+    # The step contains everything a batch needs: both K1 paths renumber the batch onto the contexts it uses inside the
+    # call (the intra-slice parallel kernels in their census pass; the one-lane-per-slice kernel through a census of its
+    # own and a look-up as records are loaded), nothing happens before the first step.
     prepass_ms = 0.0
-    if kind == avr.KIND_CABAC and path == "serial" and not args.full_context_table:
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        w.densify()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        prepass_ms = e0.elapsed_time(e1)
+    if args.full_context_table:
+        os.environ["AVR_NO_DENSE"] = "1"
     step = w.encode_chunked if path == "chunked" else w.encode
     if args.records == "resolved":
         if kind != avr.KIND_CABAC:
