@@ -298,3 +298,32 @@ def test_batch_of_many_short_slices_from_codes(avr, oracle):
         b.run()
         for i, (r, s) in enumerate(slices):
             assert b.get(i) == (oracle.cabac_encode(r, s)[0], 0), f"slice {i}"
+
+
+@pytest.mark.parametrize("workload,n_slices", [(3, 4096), (4, 16384)])
+def test_chunked_full_size_configs_3_and_4_sampled(avr, oracle, workload, n_slices):
+    """BASELINE.json configs[2] and configs[3] at their own size through the intra-slice parallel kernels: every status 0,
+    the same bytes on a second run, and byte equality with the oracle (and a decode round trip) on a seeded sample of
+    slices -- the whole batch is 2.8 / 4.0 G bins, more than the CPU checker does inside a test; bench.py byte-compares
+    the leading slices it times the CPU on (profiles/r02_bench_w3.json, _w4.json)."""
+    w = avr.DeviceWorkload.synth(workload, n_slices, 0, 0, 1000)
+    w.encode_chunked()
+    got, status = w.results()
+    assert not any(status)
+    lens = [len(x) for x in got]
+    w.out.zero_()
+    w.encode_chunked()
+    again, _ = w.results()
+    assert again == got
+    nb = w.n_bins.cpu().numpy()
+    sample = sorted(set(np.random.default_rng(workload).integers(0, n_slices, 24).tolist() + [0, n_slices - 1, int(nb.argmax()), int(nb.argmin())]))
+    for s in sample:
+        cfg, nbh, off, recs, states = host_synth(avr, workload, 1, 0, 1000, first=s)
+        assert int(nbh[0]) == int(nb[s])
+        r = recs[:int(nbh[0])]
+        want = oracle.cabac_encode(r, states)
+        assert got[s] == want[0], f"slice {s}"
+        if s in sample[:4]:
+            bins, _ = oracle.spec_cabac_decode(got[s], r, states)
+            assert np.array_equal(bins, r & 1)
+    assert 0.9 < w.total_bins / (8 * sum(lens)) < 1.8
