@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "avr_coder.h"
+#include "avr_div.h"
 #include "avr_internal.h"
 #include "avr_synth.h"
 #include "avr_tables.h"
@@ -254,13 +255,17 @@ __device__ __forceinline__ uint64_t div_u64_small(uint64_t n, uint32_t d, uint32
     return (uint64_t((q3 << 16) | q2) << 32) | ((q1 << 16) | q0);
 }
 
-template <bool TILED>
+// VARIANT (measurement only, AVR_K2_VARIANT): bit 0 = the integer long division, bit 1 = the range recurrence alone
+// (no low, no digits: the serial floor of this coder).  A deeper read-ahead than two chunks was
+// measured and buys nothing even at one wave per SIMD: the bin-to-bin dependency chain, not HBM latency, is the time.
+template <bool TILED, int VARIANT>
 __global__ __launch_bounds__(64) void k_range_encode(
     const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
     uint32_t n_slices, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
     __shared__ uint32_t magic[256];                              // ceil(2^32 / d)
+    __shared__ double inv_d[256];                                // fl(1 / d)
     const uint32_t lane = threadIdx.x;
-    for (uint32_t d = lane; d < 256; d += 64) magic[d] = d >= 2 ? 0xffffffffu / d + 1 : 0;
+    for (uint32_t d = lane; d < 256; d += 64) { magic[d] = d >= 2 ? 0xffffffffu / d + 1 : 0; inv_d[d] = d ? 1.0 / double(d) : 0.0; }
     __syncthreads();
     const uint32_t g = blockIdx.x * 64 + lane;
     if (g >= n_slices) return;
@@ -276,36 +281,54 @@ __global__ __launch_bounds__(64) void k_range_encode(
 
     const ChunkSource<TILED> src(recs, off, g, slice);
     const uint32_t n_chunks = (nb + 7) >> 3;
-    const uint4 nop4 = make_uint4(0, 0, 0, 0);
-    uint4 cur = n_chunks > 0 ? src.load(0) : nop4;
-    uint4 nx1 = n_chunks > 1 ? src.load(1) : nop4;
     bool dead = false;
-    for (uint32_t c = 0; c < n_chunks && !dead; c++) {
-        const uint4 nx2 = (c + 2 < n_chunks) ? src.load(c + 2) : nop4;
-        uint32_t w0 = cur.x, w1 = cur.y, w2 = cur.z, w3 = cur.w;
-#pragma unroll 1
-        for (uint32_t k = 0; k < 8 && !dead; k++) {
-            const uint32_t rec = w0 & 0xffffu;
-            w0 = (w0 >> 16) | (w1 << 16); w1 = (w1 >> 16) | (w2 << 16); w2 = (w2 >> 16) | (w3 << 16); w3 >>= 16;
-            const uint32_t bin = rec & 1, pos = (rec >> 1) & 0x7f, neg = (rec >> 8) & 0x7f;
-            const uint32_t total = pos + neg;                    // recode.cpp:825
-            if (total == 0) continue;                            // no-op (padding) record
-            const uint64_t quot = total == 1 ? e.range : div_u64_small(e.range, total, magic[total]);
-            const uint64_t r1 = quot * pos;                      // recode.cpp:826
+    // The operands of a chunk's eight bins (bin, pos, 1/total from LDS) depend on the records alone: they are all
+    // fetched before the first bin is coded, so no LDS latency sits on the range -> range chain.
+    auto code_chunk = [&](const uint4 cur) {
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t bin[8], pos[8], tot[8];
+        double inv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t rec = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            pos[k] = (rec >> 1) & 0x7f;
+            tot[k] = pos[k] + ((rec >> 8) & 0x7f);               // recode.cpp:825
+            bin[k] = tot[k] ? rec & 1 : 0;                       // total 0: a no-op (padding) record, whatever its bin
+            inv[k] = inv_d[tot[k]];                              // 0 for total 0: quotient 0, range unchanged
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (dead) break;
+            const uint64_t quot = (VARIANT & 1) ? (tot[k] < 2 ? (tot[k] ? e.range : 0) : div_u64_small(e.range, tot[k], magic[tot[k]]))
+                                                : div_u64_small_f64(e.range, double(tot[k]), inv[k]);
+            const uint64_t r1 = quot * pos[k];                   // recode.cpp:826
             const uint64_t r0 = e.range - r1;                    // arithmetic_code.h:108
-            e.low += bin ? r0 : 0;
-            e.range = bin ? r1 : r0;
+            if (!(VARIANT & 2)) e.low += bin[k] ? r0 : 0;
+            e.range = bin[k] ? r1 : r0;
             if (e.range < (uint64_t(1) << 51)) {                 // min_range, arithmetic_code.h:61-62,115
                 if (e.range == 0) { st = AVR_SLICE_ZERO_PROB; dead = true; }           // :116-118
+                else if (VARIANT & 2) do { e.range <<= 8; e.w.n++; } while (e.range < (uint64_t(1) << 55));
                 else do e.emit_digit(); while (e.range < (uint64_t(1) << 55));         // :120-122
             }
         }
+    };
+    // every load is unconditional (the index is clamped to the slice's last chunk; what a clamped load returns is never
+    // coded), so the compiler keeps counted waits instead of draining the queue at a branch
+    const uint32_t last = n_chunks ? n_chunks - 1 : 0;
+    uint4 cur = make_uint4(0, 0, 0, 0), nx1 = cur;
+    if (n_chunks) { cur = src.load(0); nx1 = src.load(min(1u, last)); }
+    for (uint32_t c = 0; c < n_chunks && !dead; c++) {
+        const uint4 nx2 = src.load(min(c + 2, last));
+        code_chunk(cur);
         cur = nx1;
         nx1 = nx2;
     }
     if (active) {
-        if (st == AVR_SLICE_OK) e.finish();                      // recode.cpp:1100
-        e.w.flush();
+        if (VARIANT & 2) e.w.n = uint32_t(e.range >> 40);
+        else {
+            if (st == AVR_SLICE_OK) e.finish();                  // recode.cpp:1100
+            e.w.flush();
+        }
         if (st == AVR_SLICE_OK && e.w.n > cap) st = AVR_SLICE_OVERFLOW;
     }
     out_len[slice] = active ? e.w.n : 0;
@@ -570,12 +593,15 @@ hipError_t launch_range_encode(bool tiled, hipStream_t s, const void *recs, cons
                                int32_t *status) {
     if (n_slices == 0) return hipSuccess;
     const dim3 grid((n_slices + 63) / 64), block(64);
-    if (tiled)
-        hipLaunchKernelGGL(k_range_encode<true>, grid, block, 0, s, recs, off, n_bins, order, n_slices,
-                           out, out_off, out_len, status);
-    else
-        hipLaunchKernelGGL(k_range_encode<false>, grid, block, 0, s, recs, off, n_bins, order, n_slices,
-                           out, out_off, out_len, status);
+    const char *v = getenv("AVR_K2_VARIANT");
+    const int variant = v ? atoi(v) : 0;
+#define AVR_K2_LAUNCH(T, V) hipLaunchKernelGGL((k_range_encode<T, V>), grid, block, 0, s, recs, off, n_bins, order, n_slices, out, out_off, out_len, status)
+    if (!tiled) AVR_K2_LAUNCH(false, 0);
+    else if (variant == 1) AVR_K2_LAUNCH(true, 1);
+    else if (variant == 2) AVR_K2_LAUNCH(true, 2);
+    else if (variant == 3) AVR_K2_LAUNCH(true, 3);
+    else AVR_K2_LAUNCH(true, 0);
+#undef AVR_K2_LAUNCH
     return hipGetLastError();
 }
 

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 
+#include "avr_div.h"
 #include "avr_k1p.h"
 #include "avr_tables.h"
 
@@ -70,6 +71,27 @@ size_t k1p_emul_encode_resolved(const uint8_t *res, size_t n, uint8_t *out, size
         info[4] = uint32_t(add.stores); info[5] = uint32_t(add.adds); info[6] = nd; info[7] = 0;
     }
     return len;
+}
+
+// avr_div.h against the CPU's own divide: n random below 2^63 + 1 (and the edges), every divisor 1..255.  Returns the
+// number of mismatches.
+uint64_t div_emul_check(uint64_t seed, uint64_t rounds) {
+    uint64_t bad = 0, x = seed * 0x9e3779b97f4a7c15ull + 1;
+    const uint64_t edges[] = {0, 1, 255, 256, 0xffffffffull, 0x100000000ull, 0x1ffffffffull, (1ull << 51) - 1, 1ull << 51, (1ull << 55) + 12345,
+                              (1ull << 63) - 1, 1ull << 63};
+    for (uint64_t r = 0; r < rounds + sizeof edges / sizeof *edges; r++) {
+        uint64_t n;
+        if (r < sizeof edges / sizeof *edges) n = edges[r];
+        else {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            n = x >> 1;                                            // < 2^63
+            if ((r & 7) == 0) n -= n % ((x >> 3) % 255 + 1);       // exact multiples: the case a biased reciprocal gets wrong
+            if ((r & 15) == 1) n = (n >> 32 << 32) | 0xffffffffull;
+        }
+        for (uint32_t d = 1; d < 256; d++)
+            if (div_u64_small_f64(n, double(d), 1.0 / double(d)) != n / d) bad++;
+    }
+    return bad;
 }
 
 }  // extern "C"

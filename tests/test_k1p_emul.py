@@ -20,11 +20,13 @@ CSRC = os.path.join(ROOT, "avrecode-ms_amd", "csrc")
 
 @pytest.fixture(scope="module")
 def emul():
-    deps = [SRC, os.path.join(CSRC, "avr_k1p.h"), os.path.join(CSRC, "avr_tables.h")]
+    deps = [SRC, os.path.join(CSRC, "avr_k1p.h"), os.path.join(CSRC, "avr_tables.h"), os.path.join(CSRC, "avr_div.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-o", SO, SRC], check=True)
     lib = ctypes.CDLL(SO)
     lib.k1p_emul_encode_resolved.restype = ctypes.c_size_t
+    lib.div_emul_check.restype = ctypes.c_uint64
+    lib.div_emul_check.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
     return lib
 
 
@@ -140,3 +142,10 @@ def test_state_transitions_are_monotone(avr):
         assert all(step(s, b) < 126 for s in states)             # pStateIdx 63 is never entered
     for s in (126, 127):                                         # ... and never left
         assert step(s, 0) == s and step(s, 1) == s
+
+
+def test_fp64_division_of_the_recoded_coder_is_exact(emul):
+    """k_range_encode's range / total (recode.cpp:826) goes through the FP64 pipe (csrc/avr_div.h); the same function on
+    the CPU against the integer divide: 200 000 dividends below 2^63 (edges, exact multiples, all-ones low words) times
+    every divisor 1..255."""
+    assert emul.div_emul_check(7, 200000) == 0
