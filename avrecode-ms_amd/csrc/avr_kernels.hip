@@ -61,7 +61,11 @@ struct ChunkSource {
 //     selectors that are no context of the batch) go to pseudo contexts whose pseudo states never move;
 //   * the pseudo states are table rows of their own: 128 bypass (flag in .y: the coded range is
 //     range / 2), 130 terminate (LPS range 2 in every range quarter, valMPS 0), 132 no-op (LPS range 0,
-//     and a flag in .y that forces symbol 0, so such a record changes nothing whatever its bin).
+//     and a flag in .y that forces symbol 0, so such a record changes nothing whatever its bin);
+//   * 134 / 135 are the no-op again, but 134's successor is 135 and 135 is its own: the pseudo context that
+//     starts in 134 reads 135 once any bin has gone through it.  That is where a context goes that the slice
+//     declares but the (sampled) census of the batch did not see -- the lane finds out at the end, at no cost
+//     per bin, and hands its slice back (AVR_SLICE_RETRY_SERIAL: coded by a second launch without renumbering).
 // Returns nothing; put_terminate(1) is found by the caller from the record value.
 struct CabacLane {
     CabacEncoder e;
@@ -90,6 +94,7 @@ struct CabacLane {
     }
 };
 
+constexpr uint32_t kCensusStride = 16;                           // the one-lane-per-slice kernel renumbers from a 1-in-16 sample
 constexpr uint32_t kK1Waves = 4;                                 // waves per workgroup (fewer when the state rows are large): they share the two tables
 
 // table / index: the dense renumbering of the batch's contexts (k_k1p_densemap), or null: contexts as the caller
@@ -101,34 +106,41 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const uint16_t *table, const uint16_t *index, uint32_t n_rows,
     uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
     uint8_t *final_states, int32_t want_status) {
-    extern __shared__ uint32_t lds[];                            // per wave: state dwords [(n_rows + 3 + 3) / 4][64]
+    extern __shared__ uint32_t lds[];                            // per wave: state dwords [(n_rows + 4 + 3) / 4][64]
     __shared__ uint2 tab[136];                                   // 128 states + pseudo-states 128..135
     __shared__ uint32_t sel_off[2048];                           // selector -> byte offset of its state in the lane's column (up to 256 rows of 256 bytes, + 3)
 
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t rows4 = (n_rows + 3 + 3) >> 2;                // contexts, then three pseudo contexts
+    const uint32_t rows4 = (n_rows + 4 + 3) >> 2;                // contexts, then four pseudo contexts
     uint32_t *st32 = lds + wv * rows4 * 64;
     uint8_t *st_lane = reinterpret_cast<uint8_t *>(st32) + lane * 4;
-    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x)
-        tab[i] = make_uint2(d_tables.packed[i][0], d_tables.packed[i][1]);
-    if (threadIdx.x < 8) {                                       // 128: bypass, 130: terminate (LPS range 2), 132: no-op; each is its own successor
-        const uint32_t st = 128 + threadIdx.x;
-        tab[st] = make_uint2(threadIdx.x == 2 ? 0x02020202u : 0u, (threadIdx.x == 0 ? 0x80000000u : threadIdx.x == 4 ? 0x40000000u : 0u) | st | st << 8);
-    }
-    for (uint32_t sel = threadIdx.x; sel < 2048; sel += blockDim.x) {
-        uint32_t k;
-        if (sel < 1024) { const uint32_t d = table ? uint32_t(table[sel]) : (sel < n_states ? sel : 0xffffu); k = d < n_rows ? d : n_rows + 2; }
-        else k = sel == AVR_SEL_BYPASS ? n_rows : sel == AVR_SEL_TERMINATE ? n_rows + 1 : n_rows + 2;
-        sel_off[sel] = ((k >> 2) << 8) + (k & 3);
-    }
-
     const bool in_range = g < n_slices;
     const uint32_t slice = in_range ? (order ? order[g] : g) : 0;
     // Only slices whose status is `want_status` are coded: AVR_SLICE_OK in the normal case (a slice
-    // flagged by the packer is skipped), AVR_SLICE_RETRY_SERIAL when K1p hands slices back.
+    // flagged by the packer is skipped), AVR_SLICE_RETRY_SERIAL when slices are handed back (by K1p, or by
+    // the renumbered launch of this kernel).  A workgroup without any leaves before it fills a table.
     int32_t st = in_range ? status[slice] : AVR_SLICE_OK;
     const bool active = in_range && st == want_status;
+    if (!__syncthreads_or(active)) {
+        if (in_range && want_status == AVR_SLICE_OK) out_len[slice] = 0;
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x)
+        tab[i] = make_uint2(d_tables.packed[i][0], d_tables.packed[i][1]);
+    if (threadIdx.x < 8) {                                       // 128: bypass, 130: terminate (LPS range 2), 132 / 134 / 135: no-op
+        const uint32_t t = threadIdx.x, ps = 128 + t, next = t == 6 ? 135u : ps;
+        tab[ps] = make_uint2(t == 2 ? 0x02020202u : 0u, (t == 0 ? 0x80000000u : t >= 4 ? 0x40000000u : 0u) | next | next << 8);
+    }
+    for (uint32_t sel = threadIdx.x; sel < 2048; sel += blockDim.x) {
+        uint32_t k;
+        if (sel < 1024) {                                        // a context of the slice that has no row: the census missed it
+            const uint32_t d = table ? uint32_t(table[sel]) : (sel < n_states ? sel : 0xffffu);
+            k = d < n_rows ? d : sel < n_states ? n_rows + 3 : n_rows + 2;
+        } else k = sel == AVR_SEL_BYPASS ? n_rows : sel == AVR_SEL_TERMINATE ? n_rows + 1 : n_rows + 2;
+        sel_off[sel] = ((k >> 2) << 8) + (k & 3);
+    }
+
     if (active) st = AVR_SLICE_OK;
     const uint32_t nb = active ? n_bins[slice] : 0;
 
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
             uint32_t v = 0;
             for (uint32_t b = 0; b < 4; b++) {
                 const uint32_t k = 4 * k4 + b;
-                uint32_t sv = k == n_rows ? 128u : k == n_rows + 1 ? 130u : 132u;     // the pseudo contexts (and the padding of the last dword)
+                uint32_t sv = k == n_rows ? 128u : k == n_rows + 1 ? 130u : k == n_rows + 3 ? 134u : 132u;   // the pseudo contexts (and padding)
                 if (k < n_rows && active) sv = src[index ? uint32_t(index[k]) : k];
                 v |= sv << (8 * b);
             }
@@ -181,14 +193,16 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     }
     if (in_range) {
         if (active) {
+            const bool missed = st_lane[(((n_rows + 3) >> 2) << 8) + ((n_rows + 3) & 3)] == 135u;
             if (term_at != 0xffffffffu && term_at + 1 < nb) st = AVR_SLICE_BAD_RECORD;   // a bin after finish()
             else L.e.finish();                                   // cabac_code.h:63-65 / ~encoder(), arithmetic_code.h:100
             L.e.w.flush();
             if (st == AVR_SLICE_OK && L.e.w.n > cap) st = AVR_SLICE_OVERFLOW;
+            if (missed) { st = AVR_SLICE_RETRY_SERIAL; L.e.w.n = 0; }   // whatever else: the bytes are not the slice's
         }
         if (active) { out_len[slice] = L.e.w.n; status[slice] = st; }
         else if (want_status == AVR_SLICE_OK) out_len[slice] = 0;
-        if (final_states && active) {                            // final_states starts out as a copy of init_states when a renumbering is in use
+        if (final_states && active && st != AVR_SLICE_RETRY_SERIAL) {                            // final_states starts out as a copy of init_states when a renumbering is in use
             uint8_t *dst = final_states + size_t(slice) * n_states;
             const uint8_t *col = reinterpret_cast<const uint8_t *>(st32) + lane * 4;
             for (uint32_t k = 0; k < n_rows; k++) dst[index ? uint32_t(index[k]) : k] = col[((k >> 2) << 8) + (k & 3)];
@@ -199,9 +213,13 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
 // Which contexts the records of a tile / a slice use (one bit per selector < 1024): the census behind the dense
 // renumbering, for the one-lane-per-slice kernel.  One workgroup per 64 slices; plain LDS flag stores, then the
 // global words are only touched while a bit is still missing (see k_k1p_census).
+//
+// `stride` > 1: a sample -- every stride-th 16-byte chunk of each slice (a tile's chunk rows r with r % stride ==
+// tile % stride).  The renumbering only has to hold the contexts that matter for the LDS footprint; a slice with a
+// bin in a context the sample missed is handed back by k_cabac_encode and coded by the launch without renumbering.
 template <bool TILED>
 __global__ __launch_bounds__(256) void k_k1_census(const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
-                                                   uint32_t n_slices, uint32_t *used) {
+                                                   uint32_t n_slices, uint32_t *used, uint32_t stride) {
     __shared__ uint8_t flag[1024];
     __shared__ uint32_t bm[32];
     reinterpret_cast<uint32_t *>(flag)[threadIdx.x] = 0;
@@ -217,8 +235,8 @@ __global__ __launch_bounds__(256) void k_k1_census(const void *recs, const uint6
     };
     if (TILED) {                                                 // the tile is one contiguous run of 16-byte chunks
         const uint4 *p = reinterpret_cast<const uint4 *>(recs) + off[blockIdx.x];
-        const uint64_t n = off[blockIdx.x + 1] - off[blockIdx.x];
-        for (uint64_t i = threadIdx.x; i < n; i += 256) take(p[i]);
+        const uint64_t rows = (off[blockIdx.x + 1] - off[blockIdx.x]) >> 6;      // 64 chunks (one per lane) to a row
+        for (uint64_t r = blockIdx.x % stride + uint64_t(stride) * (threadIdx.x >> 6); r < rows; r += 4 * stride) take(p[r * 64 + (threadIdx.x & 63)]);
     } else {
         for (uint32_t l = 0; l < 64; l++) {
             const uint32_t g = blockIdx.x * 64 + l;
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(256) void k_k1_census(const void *recs, const uint6
             const uint32_t slice = order ? order[g] : g;
             const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(recs) + off[slice]);
             const uint32_t n = (n_bins[slice] + 7) >> 3;
-            for (uint32_t i = threadIdx.x; i < n; i += 256) take(p[i]);
+            for (uint32_t i = (blockIdx.x + l) % stride + stride * threadIdx.x; i < n; i += 256 * stride) take(p[i]);
         }
     }
     __syncthreads();
@@ -551,14 +569,18 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
     uint32_t n_rows = n_states;
     uint8_t *scratch = nullptr;                                  // used[32] + n_dense | table[1024] | index[1024]
     const uint16_t *table = nullptr, *index = nullptr;
+    bool retry = false;                                          // the census was a sample: a second launch takes what it missed
     if (dense && want_status == AVR_SLICE_OK && n_states > 8 && !getenv("AVR_NO_DENSE")) {
         if ((err = hipMallocAsync(reinterpret_cast<void **>(&scratch), 256 + 4096, s)) != hipSuccess) return err;
         uint32_t *used = reinterpret_cast<uint32_t *>(scratch);
         uint16_t *t = reinterpret_cast<uint16_t *>(scratch + 256);
         if ((err = hipMemsetAsync(used, 0, 256, s)) != hipSuccess) return err;
         const dim3 cgrid((n_slices + 63) / 64);
-        if (tiled) hipLaunchKernelGGL(k_k1_census<true>, cgrid, dim3(256), 0, s, recs, off, n_bins, order, n_slices, used);
-        else hipLaunchKernelGGL(k_k1_census<false>, cgrid, dim3(256), 0, s, recs, off, n_bins, order, n_slices, used);
+        const char *cs = getenv("AVR_CENSUS_STRIDE");
+        const uint32_t stride = cs && atoi(cs) > 0 ? uint32_t(atoi(cs)) : kCensusStride;
+        retry = stride > 1;
+        if (tiled) hipLaunchKernelGGL(k_k1_census<true>, cgrid, dim3(256), 0, s, recs, off, n_bins, order, n_slices, used, stride);
+        else hipLaunchKernelGGL(k_k1_census<false>, cgrid, dim3(256), 0, s, recs, off, n_bins, order, n_slices, used, stride);
         if ((err = launch_densemap(s, used, t, t + 1024, used + 32)) != hipSuccess) return err;
         uint32_t nd = 0;
         if ((err = hipMemcpyAsync(&nd, used + 32, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return err;
@@ -571,18 +593,22 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
         if (final_states && (err = hipMemcpyAsync(final_states, init_states, size_t(n_slices) * n_states, hipMemcpyDeviceToDevice, s)) != hipSuccess)
             return err;                                          // contexts without bins keep their state
     }
-    const uint32_t per_wave = ((n_rows + 3 + 3) / 4) * 256;
-    const uint32_t waves = per_wave * kK1Waves <= 60 * 1024 ? kK1Waves : per_wave * 2 <= 60 * 1024 ? 2 : 1;
-    const uint32_t lds = waves * per_wave;
-    const dim3 grid((n_slices + 64 * waves - 1) / (64 * waves)), block(64 * waves);
-    auto kern = tiled ? k_cabac_encode<true> : k_cabac_encode<false>;
-    if (lds > 48 * 1024) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (err != hipSuccess) return err;
-    }
-    hipLaunchKernelGGL(kern, grid, block, lds, s, recs, off, n_bins, order, n_slices, init_states, n_states, table, index, n_rows, out,
-                       out_off, out_len, status, final_states, want_status);
-    err = hipGetLastError();
+    auto launch = [&](uint32_t rows, const uint16_t *tb, const uint16_t *ix, int32_t want) -> hipError_t {
+        const uint32_t per_wave = ((rows + 4 + 3) / 4) * 256;
+        const uint32_t waves = per_wave * kK1Waves <= 60 * 1024 ? kK1Waves : per_wave * 2 <= 60 * 1024 ? 2 : 1;
+        const uint32_t lds = waves * per_wave;
+        const dim3 grid((n_slices + 64 * waves - 1) / (64 * waves)), block(64 * waves);
+        auto kern = tiled ? k_cabac_encode<true> : k_cabac_encode<false>;
+        if (lds > 48 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, block, lds, s, recs, off, n_bins, order, n_slices, init_states, n_states, tb, ix, rows, out,
+                           out_off, out_len, status, final_states, want);
+        return hipGetLastError();
+    };
+    err = launch(n_rows, table, index, want_status);
+    if (err == hipSuccess && retry) err = launch(n_states, nullptr, nullptr, AVR_SLICE_RETRY_SERIAL);
     if (scratch) { const hipError_t e2 = hipFreeAsync(scratch, s); if (err == hipSuccess) err = e2; }
     return err;
 }

@@ -83,6 +83,31 @@ def test_cabac_random_ragged(avr, oracle, n_states):
         assert got == oracle.cabac_encode(recs, st), f"slice {i} n={len(recs)}"
 
 
+@pytest.mark.parametrize("stride", ["1", "16", "1000003"])
+def test_cabac_census_sample_and_hand_back(avr, oracle, stride, monkeypatch):
+    """The one-lane-per-slice kernel renumbers the batch's contexts from a SAMPLE of the records (every 16th chunk); a
+    slice with a bin in a context the sample missed comes back from the first launch as 'retry' and is coded by the
+    second, unrenumbered one.  Same bytes, final states and statuses whatever the sample saw: the full census (1), the
+    shipped stride (16: the 1024-context streams here have many contexts that occur once or twice, so a good part of
+    the slices takes the second launch), and a stride that samples next to nothing (every slice handed back)."""
+    monkeypatch.setenv("AVR_CENSUS_STRIDE", stride)
+    monkeypatch.setenv("AVR_K1_PATH", "serial")
+    rng = np.random.default_rng(77)
+    slices = []
+    for i in range(300):
+        n = int(rng.integers(0, 4000)) if i % 7 else int(rng.integers(0, 9))
+        recs, st = oracle_lib.random_cabac_stream(rng, n, 1024, terminate=(i % 5 != 0))
+        sel = recs >> 1
+        recs = np.where((sel >= 900) & (sel < 1024), ((sel % 900) << 1) | (recs & 1), recs).astype(np.uint16)   # contexts 900..1023: unused ...
+        if i % 40 == 5 and n > 10:                     # ... but for single bins in a few slices, which no 1-in-16 sample is likely to see
+            recs[n // 2] = np.uint16(((1000 + i // 40) << 1) | (i & 1))
+            recs[n - 3] = np.uint16((1023 << 1) | 1)
+        slices.append((recs, st))
+    res = run_cabac_batch(avr, slices)
+    for i, ((recs, st), got) in enumerate(zip(slices, res)):
+        assert got == oracle.cabac_encode(recs, st), f"slice {i} n={len(recs)}"
+
+
 def test_range_random_ragged(avr, oracle):
     rng = np.random.default_rng(77)
     slices = [oracle_lib.random_range_stream(rng, int(rng.integers(0, 2500)), adaptive=bool(i % 2)) for i in range(150)]

@@ -42,7 +42,7 @@ def per_kernel(path, counter, steps_key="avr::"):
 
 traffic = {}
 for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches of one step"),
-                      (5, "cabac_serial_w5_s1048576", "k_cabac_encode<tiled>")):
+                      (5, "cabac_serial_w5_s1048576", "k_k1_census + k_k1p_densemap + k_cabac_encode<tiled>: all launches of one step")):
     shutil.copy(one(f"w{w}_stats/**/*kernel_stats.csv"), os.path.join(dst, f"{rnd}_w{w}_kernel_stats.csv"))
     for what in ("fetch", "write"):
         rows = [r for r in csv.DictReader(open(one(f"w{w}_{what}/**/*counter_collection.csv"))) if "avr::" in r["Kernel_Name"]]
@@ -74,13 +74,14 @@ for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches o
         for k in sorted({k[0] for k in agg}):
             wr.writerow([k] + ["%.6g" % (agg[(k, c)] / max(cnt[(k, c)], 1)) for c in names])
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-for b in ("w2", "w3", "w4", "w5", "w5_k2", "w2_resolved"):
+json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
+for b in ("w2", "w3", "w4", "w5", "w5_k2", "w2_resolved", "w2_k2", "w4_k2"):
     p = os.path.join(src, f"bench_{b}.json")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{rnd}_bench_{b}.json"))
 for key, t in traffic.items():
     print(key, "HBM bytes per step: %.3f GB" % (t["hbm_bytes_per_launch"] / 1e9))
-for b in ("w2", "w3", "w4", "w5", "w5_k2", "w2_resolved"):
+for b in ("w2", "w3", "w4", "w5", "w5_k2", "w2_resolved", "w2_k2", "w4_k2"):
     p = os.path.join(dst, f"{rnd}_bench_{b}.json")
     if os.path.exists(p):
         j = json.loads(open(p).read().strip().splitlines()[-1])

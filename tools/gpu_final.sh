@@ -13,6 +13,8 @@ python3 $R/bench.py --workload 4 > $O/bench_w4.json 2>> $O/bench.err || exit 1
 python3 $R/bench.py --workload 5 > $O/bench_w5.json 2>> $O/bench.err || exit 1
 python3 $R/bench.py --workload 5 --kind range > $O/bench_w5_k2.json 2>> $O/bench.err || exit 1
 python3 $R/bench.py --records resolved --no-cpu-baseline > $O/bench_w2_resolved.json 2>> $O/bench.err || exit 1
+python3 $R/bench.py --workload 2 --kind range --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_w2_k2.json 2>> $O/bench.err || exit 1
+python3 $R/bench.py --workload 4 --kind range --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_w4_k2.json 2>> $O/bench.err || exit 1
 echo benches done
 for W in 2 5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/w${W}_stats -- python3 $R/bench.py --no-cpu-baseline --workload $W --steps 5 --warmup 1 > /dev/null 2>&1 || exit 1
