@@ -27,7 +27,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libavrecode_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avrecode_ms_amd.h")
 
-KIND_CABAC, KIND_RANGE = 0, 1
+KIND_CABAC, KIND_RANGE, KIND_CABAC_CODES = 0, 1, 2
 SEL_BYPASS, SEL_TERMINATE = 1024, 1025
 SLICE_OK, SLICE_ZERO_PROB, SLICE_OVERFLOW, SLICE_BAD_RECORD = 0, 1, 2, 3
 NOP_CABAC, NOP_RANGE = 1026 << 1, 0
@@ -115,10 +115,14 @@ SIGNATURES = {
     "avr_batch_add_slice_cabac": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
     "avr_batch_add_slice_range": (c_int, [c_void_p, c_void_p, c_size_t]),
     "avr_batch_add_slice_codes": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "avr_batch_reserve_slice": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_size_t, POINTER(c_void_p)]),
+    "avr_batch_submit": (c_int, [c_void_p]),
+    "avr_batch_wait": (c_int, [c_void_p]),
     "avr_batch_run": (c_int, [c_void_p]),
     "avr_batch_get": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t), POINTER(c_int)]),
     "avr_batch_get_states": (c_int, [c_void_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]),
     "avr_batch_timings": (c_int, [c_void_p, POINTER(c_float)]),
+    "avr_batch_run_info": (c_int, [c_void_p, POINTER(ctypes.c_uint32)]),
     "avr_multi_create": (c_void_p, [c_void_p, c_size_t, c_size_t, c_size_t]),
     "avr_multi_destroy": (None, [c_void_p]),
     "avr_multi_add_slice_cabac": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
@@ -279,6 +283,29 @@ class Batch:
         import numpy as np
         c = np.ascontiguousarray(codes, dtype=np.uint8)
         return _check(self._L.avr_batch_add_slice_codes(self._h, c.ctypes.data, c.size))
+
+    def reserve(self, kind: int, n: int, init_states=None):
+        """Zero-copy add: (slice index, numpy view of n elements in the batch's pinned staging buffer)."""
+        import numpy as np
+        st = None if init_states is None else np.ascontiguousarray(init_states, dtype=np.uint8)
+        p = c_void_p()
+        idx = _check(self._L.avr_batch_reserve_slice(self._h, kind, n, None if st is None else st.ctypes.data,
+                                                     0 if st is None else st.size, ctypes.byref(p)))
+        ctype = ctypes.c_uint8 if kind == KIND_CABAC_CODES else ctypes.c_uint16
+        view = np.ctypeslib.as_array(ctypes.cast(p.value, POINTER(ctype)), shape=(n,)) if n else np.zeros(0, ctype)
+        return idx, view
+
+    def run_info(self):
+        """{'chunked', 'rows_guessed', 'contexts_seen', 'ran_again'} of the last run."""
+        v = (ctypes.c_uint32 * 4)()
+        _check(self._L.avr_batch_run_info(self._h, v))
+        return {"chunked": int(v[0]), "rows_guessed": int(v[1]), "contexts_seen": int(v[2]), "ran_again": int(v[3])}
+
+    def submit(self):
+        _check(self._L.avr_batch_submit(self._h))
+
+    def wait(self):
+        _check(self._L.avr_batch_wait(self._h))
 
     def run(self):
         _check(self._L.avr_batch_run(self._h))

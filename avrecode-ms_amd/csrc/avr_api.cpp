@@ -137,8 +137,29 @@ struct avr_batch {
     DevBuf<uint32_t> d_chunk_base, d_chunk_slice, d_blk_base, d_blk_slice;
     DevBuf<uint8_t> d_workspace;
     int last_path = 0;                      // 0 = one lane per slice, 1 = chunked
+
+    // submit / wait: nothing the device reads may be pageable or local to a call
+    PinBuf<uint8_t> h_plan;                 // the plan arrays of the run in flight
+    size_t plan_used = 0;
+    PinBuf<uint32_t> h_ndense;              // [0]: contexts the batch uses, read back behind the kernels
+    std::vector<uint64_t> out_off;          // n+1, bytes in d_out
+    bool in_flight = false;
+    uint32_t dense_hint = 0;                // context rows the previous run of this object needed (0: no run yet)
+    uint32_t hint_used = 0;                 // what the run in flight was sized by (0: it asked the device and waited)
+    uint32_t info[4] = {0, 0, 0, 0};        // avr_batch_run_info
 };
 
+// One plan array to the device through the batch's pinned arena: the copy is asynchronous for real (a copy from
+// pageable memory is staged by the runtime inside the call), and the source stays put until avr_batch_wait.
+template <class T>
+static int stage_h2d(avr_batch *b, T *dst, const T *src, size_t n) {
+    const size_t bytes = n * sizeof(T), at = (b->plan_used + 63) & ~size_t(63);
+    if (at + bytes > b->h_plan.cap) return fail(AVR_ERR_NOMEM, "plan staging area too small (%zu + %zu > %zu)", at, bytes, b->h_plan.cap);
+    memcpy(b->h_plan.p + at, src, bytes);
+    b->plan_used = at + bytes;
+    AVR_HIP(hipMemcpyAsync(dst, b->h_plan.p + at, bytes, hipMemcpyHostToDevice, b->stream));
+    return AVR_OK;
+}
 extern "C" {
 
 const char *avr_last_error(void) { return g_err; }
@@ -182,7 +203,7 @@ void avr_batch_destroy(avr_batch *b) {
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     b->h_recs.release(); b->h_states.release(); b->h_out.release(); b->h_final.release();
-    b->h_out_len.release(); b->h_status.release();
+    b->h_out_len.release(); b->h_status.release(); b->h_plan.release(); b->h_ndense.release();
     b->d_recs.release(); b->d_tiles.release(); b->d_rec_off.release(); b->d_tile_off.release();
     b->d_out_off.release(); b->d_dense_off.release(); b->d_n_bins.release(); b->d_order.release();
     b->d_out_len.release(); b->d_status.release(); b->d_states.release(); b->d_final.release();
@@ -196,6 +217,7 @@ void avr_batch_destroy(avr_batch *b) {
 
 int avr_batch_reset(avr_batch *b) {
     if (!b) return fail(AVR_ERR_INVALID, "null batch");
+    if (b->in_flight) return fail(AVR_ERR_INVALID, "batch is in flight; call avr_batch_wait first");
     b->kind = -1; b->n_states = 0; b->ran = false; b->total_bins = 0;
     b->rec_off.assign(1, 0);
     b->n_bins.clear();
@@ -203,13 +225,16 @@ int avr_batch_reset(avr_batch *b) {
     return AVR_OK;
 }
 
-static int add_slice(avr_batch *b, int kind, const uint16_t *recs, size_t n, const uint8_t *init_states, size_t n_states) {
+// Room for one more slice in the pinned staging buffer (padding written); *where = its first element.
+static int reserve_slice(avr_batch *b, int kind, size_t n, const uint8_t *init_states, size_t n_states, void **where) {
     if (!b) return fail(AVR_ERR_INVALID, "null batch");
-    if (!recs && n) return fail(AVR_ERR_INVALID, "null records");
+    if (b->in_flight) return fail(AVR_ERR_INVALID, "batch is in flight; call avr_batch_wait first");
     if (b->ran) return fail(AVR_ERR_INVALID, "batch already ran; call avr_batch_reset first");
+    if (kind != AVR_KIND_CABAC && kind != AVR_KIND_RANGE && kind != AVR_KIND_CABAC_CODES) return fail(AVR_ERR_INVALID, "unknown kind %d", kind);
     if (b->kind >= 0 && b->kind != kind) return fail(AVR_ERR_INVALID, "a batch holds slices of one kind only");
     if (n > 0xfffffff0u) return fail(AVR_ERR_INVALID, "slice too long");
     if (b->n_bins.size() >= b->max_slices) return fail(AVR_ERR_CAPACITY, "batch holds max_slices=%zu slices", b->max_slices);
+    if (b->total_bins + n > b->max_bins) return fail(AVR_ERR_CAPACITY, "batch holds max_bins=%zu records", b->max_bins);
     const size_t idx = b->n_bins.size();
     if (kind == AVR_KIND_CABAC) {
         if (n_states > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "n_states %zu > %d", n_states, AVR_MAX_STATES);
@@ -222,56 +247,68 @@ static int add_slice(avr_batch *b, int kind, const uint16_t *recs, size_t n, con
         if (n_states) memcpy(b->h_states.p + idx * n_states, init_states, n_states);
     }
     const uint64_t off = b->rec_off.back();
-    const uint64_t padded = (uint64_t(n) + 7) & ~uint64_t(7);
-    if (b->total_bins + n > b->max_bins)
-        return fail(AVR_ERR_CAPACITY, "batch holds max_bins=%zu records", b->max_bins);
+    if (kind == AVR_KIND_CABAC_CODES) {
+        // Resolved codes live in the same pinned buffer as records would, as bytes: slice i at byte code_off[i] (the
+        // res_off of the chunk plan: 16-byte aligned, padded with a group of its own)
+        const uint64_t padded = ((uint64_t(n) + 15) & ~uint64_t(15)) + 16;
+        if (off + padded > (b->max_bins + 16 * b->max_slices) * sizeof(uint16_t))
+            return fail(AVR_ERR_CAPACITY, "batch code buffer full (%zu slices)", b->n_bins.size());
+        uint8_t *dst = reinterpret_cast<uint8_t *>(b->h_recs.p) + off;
+        memset(dst + n, AVR_CODE_BYPASS(0), padded - n);         // the padding value of a resolved stream (bypass 0, never coded)
+        b->rec_off.push_back(off + padded);
+        *where = dst;
+    } else {
+        const uint64_t padded = (uint64_t(n) + 7) & ~uint64_t(7);
+        for (uint64_t i = n; i < padded; i++) b->h_recs.p[off + i] = kind == AVR_KIND_CABAC ? AVR_NOP_CABAC : AVR_NOP_RANGE;
+        b->rec_off.push_back(off + padded);
+        *where = b->h_recs.p + off;
+    }
     b->total_bins += n;
-    if (n) memcpy(b->h_recs.p + off, recs, n * sizeof(uint16_t));
-    for (uint64_t i = n; i < padded; i++) b->h_recs.p[off + i] = kind == AVR_KIND_CABAC ? AVR_NOP_CABAC : AVR_NOP_RANGE;
-    b->rec_off.push_back(off + padded);
     b->n_bins.push_back(uint32_t(n));
     b->kind = kind;
     return int(idx);
 }
 
+int avr_batch_reserve_slice(avr_batch *b, int kind, size_t n, const uint8_t *init_states, size_t n_states, void **buffer) {
+    if (!buffer) return fail(AVR_ERR_INVALID, "null buffer pointer");
+    return reserve_slice(b, kind, n, init_states, n_states, buffer);
+}
+
 int avr_batch_add_slice_cabac(avr_batch *b, const uint16_t *recs, size_t n, const uint8_t *init_states, size_t n_states) {
-    return add_slice(b, AVR_KIND_CABAC, recs, n, init_states, n_states);
+    if (!recs && n) return fail(AVR_ERR_INVALID, "null records");
+    void *dst = nullptr;
+    const int idx = reserve_slice(b, AVR_KIND_CABAC, n, init_states, n_states, &dst);
+    if (idx >= 0 && n) memcpy(dst, recs, n * sizeof(uint16_t));
+    return idx;
 }
 
 int avr_batch_add_slice_range(avr_batch *b, const uint16_t *recs, size_t n) {
-    return add_slice(b, AVR_KIND_RANGE, recs, n, nullptr, 0);
+    if (!recs && n) return fail(AVR_ERR_INVALID, "null records");
+    void *dst = nullptr;
+    const int idx = reserve_slice(b, AVR_KIND_RANGE, n, nullptr, 0, &dst);
+    if (idx >= 0 && n) memcpy(dst, recs, n * sizeof(uint16_t));
+    return idx;
 }
 
-// Resolved codes live in the same pinned buffer as records would, as bytes: slice i at byte
-// code_off[i] (the res_off of the chunk plan: 16-byte aligned, padded with a group of its own).
 int avr_batch_add_slice_codes(avr_batch *b, const uint8_t *codes, size_t n) {
-    if (!b) return fail(AVR_ERR_INVALID, "null batch");
     if (!codes && n) return fail(AVR_ERR_INVALID, "null codes");
-    if (b->ran) return fail(AVR_ERR_INVALID, "batch already ran; call avr_batch_reset first");
-    if (b->kind >= 0 && b->kind != AVR_KIND_CABAC_CODES) return fail(AVR_ERR_INVALID, "a batch holds slices of one kind only");
-    if (n > 0xfffffff0u) return fail(AVR_ERR_INVALID, "slice too long");
-    if (b->n_bins.size() >= b->max_slices) return fail(AVR_ERR_CAPACITY, "batch holds max_slices=%zu slices", b->max_slices);
-    if (b->total_bins + n > b->max_bins) return fail(AVR_ERR_CAPACITY, "batch holds max_bins=%zu records", b->max_bins);
-    const uint64_t off = b->rec_off.back(), padded = ((uint64_t(n) + 15) & ~uint64_t(15)) + 16;
-    if (off + padded > (b->max_bins + 16 * b->max_slices) * sizeof(uint16_t))
-        return fail(AVR_ERR_CAPACITY, "batch code buffer full (%zu slices)", b->n_bins.size());
-    uint8_t *dst = reinterpret_cast<uint8_t *>(b->h_recs.p) + off;
-    if (n) memcpy(dst, codes, n);
-    memset(dst + n, AVR_CODE_BYPASS(0), padded - n);             // the padding value of a resolved stream (bypass 0, never coded)
-    b->total_bins += n;
-    b->rec_off.push_back(off + padded);
-    b->n_bins.push_back(uint32_t(n));
-    b->kind = AVR_KIND_CABAC_CODES;
-    return int(b->n_bins.size()) - 1;
+    void *dst = nullptr;
+    const int idx = reserve_slice(b, AVR_KIND_CABAC_CODES, n, nullptr, 0, &dst);
+    if (idx >= 0 && n) memcpy(dst, codes, n);
+    return idx;
 }
 
-static int fetch_output(avr_batch *b, const std::vector<uint64_t> &out_off, uint32_t n32);
+#define AVR_STAGE(dst, src, n) do { if (int rc_ = stage_h2d(b, dst, src, n)) return rc_; } while (0)
 
-// A batch of resolved codes: H2D of one byte per bin, K1p phases B-D, D2H.
-static int run_codes(avr_batch *b, uint32_t n32) {
+static int enqueue_lengths(avr_batch *b, uint32_t n32);
+
+// A batch of resolved codes: H2D of one byte per bin, K1p phases B-D (or the one-lane-per-slice coder), lengths back.
+static int submit_codes(avr_batch *b, uint32_t n32) {
     const size_t n = n32;
-    std::vector<uint64_t> out_off(n + 1, 0), dig_off(n + 1, 0);
+    std::vector<uint64_t> &out_off = b->out_off;
+    std::vector<uint64_t> dig_off(n + 1, 0);
     std::vector<uint32_t> chunk_base(n + 1, 0), chunk_slice;
+    out_off.assign(n + 1, 0);
     for (size_t i = 0; i < n; i++) {
         const uint64_t nb = b->n_bins[i];
         out_off[i + 1] = out_off[i] + ((nb + 16 + 7) & ~uint64_t(7));
@@ -280,28 +317,6 @@ static int run_codes(avr_batch *b, uint32_t n32) {
         chunk_base[i + 1] = chunk_base[i] + nc;
         chunk_slice.insert(chunk_slice.end(), nc, uint32_t(i));
     }
-    const uint64_t total_codes = b->rec_off.back(), total_out = out_off.back();
-    int rc;
-    if ((rc = b->d_recs.reserve((total_codes + 64) / 2 + 1)) || (rc = b->d_res_off.reserve(n + 1)) || (rc = b->d_dig_off.reserve(n + 1)) ||
-        (rc = b->d_chunk_base.reserve(n + 1)) || (rc = b->d_chunk_slice.reserve(chunk_slice.size())) ||
-        (rc = b->d_out_off.reserve(n + 1)) || (rc = b->d_dense_off.reserve(n + 1)) || (rc = b->d_n_bins.reserve(n)) ||
-        (rc = b->d_out_len.reserve(n)) || (rc = b->d_status.reserve(n)) || (rc = b->d_out.reserve(total_out)) ||
-        (rc = b->h_out_len.reserve(n)) || (rc = b->h_status.reserve(n)))
-        return rc;
-    avr_chunk_plan plan{b->d_res_off.p, b->d_chunk_base.p, b->d_chunk_slice.p, nullptr, nullptr, b->d_dig_off.p,
-                        total_codes, dig_off.back(), chunk_base.back(), 0};
-    const size_t ws = avr::k1p_code_workspace_bytes(n, &plan);
-    if ((rc = b->d_workspace.reserve(ws + 256))) return rc;
-    hipStream_t s = b->stream;
-    AVR_HIP(hipEventRecord(b->ev[0], s));
-    AVR_HIP(hipMemcpyAsync(b->d_recs.p, b->h_recs.p, total_codes, hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_res_off.p, b->rec_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_dig_off.p, dig_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_chunk_base.p, chunk_base.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_chunk_slice.p, chunk_slice.data(), chunk_slice.size() * 4, hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_out_off.p, out_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_n_bins.p, b->n_bins.data(), n * 4, hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
     // few, long slices: the intra-slice parallel kernels; many short ones: one lane per slice (same rule as for records)
     bool chunked = n <= 32768 && b->total_bins / n >= 8192;
     if (const char *force = getenv("AVR_K1_PATH")) chunked = strcmp(force, "chunked") == 0;
@@ -309,10 +324,33 @@ static int run_codes(avr_batch *b, uint32_t n32) {
     if (!chunked) {
         std::vector<uint64_t> tile_off;
         plan_tiles(b->n_bins, order, tile_off);                  // longest first: the lanes of a wave finish together
-        if ((rc = b->d_order.reserve(n))) return rc;
-        AVR_HIP(hipMemcpyAsync(b->d_order.p, order.data(), n * 4, hipMemcpyHostToDevice, s));
     }
-    AVR_HIP(hipStreamSynchronize(s));                            // the plan vectors are pageable locals
+    const uint64_t total_codes = b->rec_off.back(), total_out = out_off.back();
+    int rc;
+    if ((rc = b->d_recs.reserve((total_codes + 64) / 2 + 1)) || (rc = b->d_res_off.reserve(n + 1)) || (rc = b->d_dig_off.reserve(n + 1)) ||
+        (rc = b->d_chunk_base.reserve(n + 1)) || (rc = b->d_chunk_slice.reserve(chunk_slice.size())) ||
+        (rc = b->d_out_off.reserve(n + 1)) || (rc = b->d_dense_off.reserve(n + 1)) || (rc = b->d_n_bins.reserve(n)) ||
+        (rc = b->d_order.reserve(n)) || (rc = b->d_out_len.reserve(n)) || (rc = b->d_status.reserve(n)) || (rc = b->d_out.reserve(total_out)) ||
+        (rc = b->h_out_len.reserve(n)) || (rc = b->h_status.reserve(n)) ||
+        (rc = b->h_plan.reserve(64 * 8 + (n + 1) * 36 + chunk_slice.size() * 4)))
+        return rc;
+    avr_chunk_plan plan{b->d_res_off.p, b->d_chunk_base.p, b->d_chunk_slice.p, nullptr, nullptr, b->d_dig_off.p,
+                        total_codes, dig_off.back(), chunk_base.back(), 0};
+    const size_t ws = avr::k1p_code_workspace_bytes(n, &plan);
+    if ((rc = b->d_workspace.reserve(ws + 256))) return rc;
+    hipStream_t s = b->stream;
+    b->plan_used = 0;
+    b->hint_used = 0;
+    AVR_HIP(hipEventRecord(b->ev[0], s));
+    AVR_HIP(hipMemcpyAsync(b->d_recs.p, b->h_recs.p, total_codes, hipMemcpyHostToDevice, s));
+    AVR_STAGE(b->d_res_off.p, b->rec_off.data(), n + 1);
+    AVR_STAGE(b->d_dig_off.p, dig_off.data(), n + 1);
+    AVR_STAGE(b->d_chunk_base.p, chunk_base.data(), n + 1);
+    AVR_STAGE(b->d_chunk_slice.p, chunk_slice.data(), chunk_slice.size());
+    AVR_STAGE(b->d_out_off.p, out_off.data(), n + 1);
+    AVR_STAGE(b->d_n_bins.p, b->n_bins.data(), n);
+    if (!chunked) AVR_STAGE(b->d_order.p, order.data(), n);
+    AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
     AVR_HIP(hipEventRecord(b->ev[1], s));
     AVR_HIP(hipEventRecord(b->ev[2], s));
     const uint8_t *d_codes = reinterpret_cast<const uint8_t *>(b->d_recs.p);
@@ -325,63 +363,66 @@ static int run_codes(avr_batch *b, uint32_t n32) {
                                                b->d_out_off.p, b->d_out_len.p, b->d_status.p));
     }
     b->last_path = chunked;
-    return fetch_output(b, out_off, n32);
+    return enqueue_lengths(b, n32);
 }
 
-int avr_batch_run(avr_batch *b) {
-    if (!b) return fail(AVR_ERR_INVALID, "null batch");
-    if (b->ran) return fail(AVR_ERR_INVALID, "batch already ran");
-    if (int rc = select_device(b->device)) return rc;
+// Everything of a run up to the lengths on their way back.  `use_hint`: size the kernels by the context count of this
+// object's previous run instead of asking the device and waiting (avr::DenseHint); avr_batch_wait checks the guess.
+static int submit_impl(avr_batch *b, bool use_hint) {
     const size_t n = b->n_bins.size();
-    b->dense_off.assign(n + 1, 0);
-    if (n == 0) { b->ran = true; return AVR_OK; }
     const uint32_t n32 = uint32_t(n);
-    if (b->kind == AVR_KIND_CABAC_CODES) return run_codes(b, n32);
+    if (b->kind == AVR_KIND_CABAC_CODES) return submit_codes(b, n32);
     const size_t ns = b->n_states;
     const bool cabac = b->kind == AVR_KIND_CABAC;
 
     std::vector<uint32_t> order;
-    std::vector<uint64_t> tile_off, out_off(n + 1, 0);
+    std::vector<uint64_t> tile_off;
+    std::vector<uint64_t> &out_off = b->out_off;
+    out_off.assign(n + 1, 0);
     plan_tiles(b->n_bins, order, tile_off);
     // worst case is 8 bits per bin for either coder ("output sizing") + stop bytes
     for (size_t i = 0; i < n; i++) out_off[i + 1] = out_off[i] + ((uint64_t(b->n_bins[i]) + 16 + 7) & ~uint64_t(7));
     const uint64_t total_recs = b->rec_off.back(), total_chunks = tile_off.back(), total_out = out_off.back();
     const size_t n_tiles = tile_off.size() - 1;
-
-    int rc;
-    if ((rc = b->d_recs.reserve(total_recs)) || (rc = b->d_tiles.reserve(total_chunks)) ||
-        (rc = b->d_rec_off.reserve(n + 1)) || (rc = b->d_tile_off.reserve(n_tiles + 1)) ||
-        (rc = b->d_out_off.reserve(n + 1)) || (rc = b->d_dense_off.reserve(n + 1)) ||
-        (rc = b->d_n_bins.reserve(n)) || (rc = b->d_order.reserve(n)) || (rc = b->d_out_len.reserve(n)) ||
-        (rc = b->d_status.reserve(n)) || (rc = b->d_out.reserve(total_out)) ||
-        (rc = b->h_out_len.reserve(n)) || (rc = b->h_status.reserve(n)))
-        return rc;
-    if (cabac && ((rc = b->d_states.reserve(n * std::max<size_t>(ns, 1))) || (rc = b->d_final.reserve(n * std::max<size_t>(ns, 1))) ||
-                  (rc = b->h_final.reserve(n * std::max<size_t>(ns, 1)))))
-        return rc;
-
-    hipStream_t s = b->stream;
-    AVR_HIP(hipEventRecord(b->ev[0], s));
-    AVR_HIP(hipMemcpyAsync(b->d_recs.p, b->h_recs.p, total_recs * sizeof(uint16_t), hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_rec_off.p, b->rec_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_tile_off.p, tile_off.data(), (n_tiles + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_out_off.p, out_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_n_bins.p, b->n_bins.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    AVR_HIP(hipMemcpyAsync(b->d_order.p, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    if (cabac && ns) AVR_HIP(hipMemcpyAsync(b->d_states.p, b->h_states.p, n * ns, hipMemcpyHostToDevice, s));
-    // the vectors above are pageable: the copies have been staged by the runtime when the calls return
-    AVR_HIP(hipEventRecord(b->ev[1], s));
-    AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
     // One lane per slice needs tens of thousands of slices to fill the chip; a batch of few, long
     // slices (a clip with one slice per frame) goes through the intra-slice parallel kernels.
     bool chunked = cabac && n <= 32768 && b->total_bins / n >= 8192;
     if (const char *force = getenv("AVR_K1_PATH")) chunked = cabac && strcmp(force, "chunked") == 0;
     b->last_path = chunked;
+
+    int rc;
+    if ((rc = b->d_recs.reserve(total_recs)) || (!chunked && (rc = b->d_tiles.reserve(total_chunks))) ||
+        (rc = b->d_rec_off.reserve(n + 1)) || (rc = b->d_tile_off.reserve(n_tiles + 1)) ||
+        (rc = b->d_out_off.reserve(n + 1)) || (rc = b->d_dense_off.reserve(n + 1)) ||
+        (rc = b->d_n_bins.reserve(n)) || (rc = b->d_order.reserve(n)) || (rc = b->d_out_len.reserve(n)) ||
+        (rc = b->d_status.reserve(n)) || (rc = b->d_out.reserve(total_out)) ||
+        (rc = b->h_out_len.reserve(n)) || (rc = b->h_status.reserve(n)) || (rc = b->h_ndense.reserve(16)))
+        return rc;
+    if (cabac && ((rc = b->d_states.reserve(n * std::max<size_t>(ns, 1))) || (rc = b->d_final.reserve(n * std::max<size_t>(ns, 1))) ||
+                  (rc = b->h_final.reserve(n * std::max<size_t>(ns, 1)))))
+        return rc;
+    const size_t n_chunks_max = size_t(b->total_bins / AVR_CHUNK_BINS) + n + 1, n_blks_max = size_t(b->total_bins / AVR_SORT_BLOCK_BINS) + n + 1;
+    if ((rc = b->h_plan.reserve(64 * 16 + (n + 1) * 64 + (n_tiles + 1) * 8 + (chunked ? (n_chunks_max + n_blks_max) * 4 : 0)))) return rc;
+
+    hipStream_t s = b->stream;
+    b->plan_used = 0;
+    const avr::DenseHint hint{use_hint ? std::min<uint32_t>(b->dense_hint, uint32_t(ns)) : 0u, b->h_ndense.p};
+    b->hint_used = hint.rows;
+    b->h_ndense.p[0] = 0;
+    AVR_HIP(hipEventRecord(b->ev[0], s));
+    AVR_HIP(hipMemcpyAsync(b->d_recs.p, b->h_recs.p, total_recs * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    AVR_STAGE(b->d_rec_off.p, b->rec_off.data(), n + 1);
+    AVR_STAGE(b->d_out_off.p, out_off.data(), n + 1);
+    AVR_STAGE(b->d_n_bins.p, b->n_bins.data(), n);
+    if (!chunked) {
+        AVR_STAGE(b->d_tile_off.p, tile_off.data(), n_tiles + 1);
+        AVR_STAGE(b->d_order.p, order.data(), n);
+    }
+    if (cabac && ns) AVR_HIP(hipMemcpyAsync(b->d_states.p, b->h_states.p, n * ns, hipMemcpyHostToDevice, s));
+    AVR_HIP(hipEventRecord(b->ev[1], s));
+    AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
     // Both K1 paths renumber the batch onto the contexts it uses themselves (the intra-slice parallel kernels inside
     // their census pass, the one-lane-per-slice kernel through launch_cabac_encode): records and states go in as they are.
-    const uint8_t *k_states = b->d_states.p;
-    uint8_t *k_final = b->d_final.p;
-    const size_t k_ns = ns;
     if (chunked) {
         std::vector<uint64_t> res_off(n + 1, 0), dig_off(n + 1, 0);
         std::vector<uint32_t> chunk_base(n + 1, 0), blk_base(n + 1, 0), chunk_slice, blk_slice;
@@ -402,51 +443,94 @@ int avr_batch_run(avr_batch *b) {
             return rc;
         avr_chunk_plan plan{b->d_res_off.p, b->d_chunk_base.p, b->d_chunk_slice.p, b->d_blk_base.p, b->d_blk_slice.p, b->d_dig_off.p,
                             res_off.back(), dig_off.back(), chunk_base.back(), blk_base.back()};
-        const size_t ws = avr::k1p_workspace_bytes(n, uint32_t(k_ns), &plan);
+        const size_t ws = avr::k1p_workspace_bytes(n, uint32_t(ns), &plan);
         if ((rc = b->d_workspace.reserve(ws + 256))) return rc;
-        AVR_HIP(hipMemcpyAsync(b->d_res_off.p, res_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
-        AVR_HIP(hipMemcpyAsync(b->d_dig_off.p, dig_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
-        AVR_HIP(hipMemcpyAsync(b->d_chunk_base.p, chunk_base.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
-        AVR_HIP(hipMemcpyAsync(b->d_blk_base.p, blk_base.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
-        AVR_HIP(hipMemcpyAsync(b->d_chunk_slice.p, chunk_slice.data(), chunk_slice.size() * 4, hipMemcpyHostToDevice, s));
-        AVR_HIP(hipMemcpyAsync(b->d_blk_slice.p, blk_slice.data(), blk_slice.size() * 4, hipMemcpyHostToDevice, s));
-        AVR_HIP(hipStreamSynchronize(s));                        // the plan vectors are pageable locals
+        AVR_STAGE(b->d_res_off.p, res_off.data(), n + 1);
+        AVR_STAGE(b->d_dig_off.p, dig_off.data(), n + 1);
+        AVR_STAGE(b->d_chunk_base.p, chunk_base.data(), n + 1);
+        AVR_STAGE(b->d_blk_base.p, blk_base.data(), n + 1);
+        AVR_STAGE(b->d_chunk_slice.p, chunk_slice.data(), chunk_slice.size());
+        AVR_STAGE(b->d_blk_slice.p, blk_slice.data(), blk_slice.size());
         AVR_HIP(hipEventRecord(b->ev[2], s));
         uint8_t *wsp = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(b->d_workspace.p) + 255) & ~uintptr_t(255));
-        AVR_HIP(avr::launch_k1p(s, b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, n32, k_states, uint32_t(k_ns), &plan, wsp,
-                                b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p, k_final));
+        AVR_HIP(avr::launch_k1p(s, b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, n32, b->d_states.p, uint32_t(ns), &plan, wsp,
+                                b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p, b->d_final.p, &hint));
     } else {
-        AVR_HIP(avr::launch_pack_tiles(s, b->kind, uint32_t(k_ns), b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, b->d_order.p, n32,
+        AVR_HIP(avr::launch_pack_tiles(s, b->kind, uint32_t(ns), b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, b->d_order.p, n32,
                                        b->d_tile_off.p, b->d_tiles.p, b->d_status.p));
         AVR_HIP(hipEventRecord(b->ev[2], s));
         if (cabac)
-            AVR_HIP(avr::launch_cabac_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, k_states,
-                                             uint32_t(k_ns), b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p, k_final));
+            AVR_HIP(avr::launch_cabac_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_states.p,
+                                             uint32_t(ns), b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p, b->d_final.p,
+                                             AVR_SLICE_OK, true, &hint));
         else
             AVR_HIP(avr::launch_range_encode(true, s, b->d_tiles.p, b->d_tile_off.p, b->d_n_bins.p, b->d_order.p, n32, b->d_out.p,
                                              b->d_out_off.p, b->d_out_len.p, b->d_status.p));
     }
-    return fetch_output(b, out_off, n32);
+    return enqueue_lengths(b, n32);
 }
 
-// lengths, statuses and final states to the host; the coded bytes gathered densely on the device, then one D2H copy
-static int fetch_output(avr_batch *b, const std::vector<uint64_t> &out_off, uint32_t n32) {
+// lengths, statuses and final states on their way to the host behind the kernels
+static int enqueue_lengths(avr_batch *b, uint32_t n32) {
     const size_t n = n32, ns = b->n_states;
     const bool with_states = b->kind == AVR_KIND_CABAC && ns;
     hipStream_t s = b->stream;
-    int rc;
     AVR_HIP(hipEventRecord(b->ev[3], s));
     AVR_HIP(hipMemcpyAsync(b->h_out_len.p, b->d_out_len.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     AVR_HIP(hipMemcpyAsync(b->h_status.p, b->d_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (with_states) AVR_HIP(hipMemcpyAsync(b->h_final.p, b->d_final.p, n * ns, hipMemcpyDeviceToHost, s));
+    return AVR_OK;
+}
+
+int avr_batch_submit(avr_batch *b) {
+    if (!b) return fail(AVR_ERR_INVALID, "null batch");
+    if (b->in_flight) return fail(AVR_ERR_INVALID, "batch is in flight; call avr_batch_wait first");
+    if (int rc = select_device(b->device)) return rc;
+    b->ran = false;                                              // a batch may be submitted again after avr_batch_wait: same slices, coded anew
+    const size_t n = b->n_bins.size();
+    b->dense_off.assign(n + 1, 0);
+    if (n == 0) { b->in_flight = true; return AVR_OK; }
+    const bool use_hint = b->dense_hint > 0 && !getenv("AVR_BATCH_NO_HINT");
+    if (int rc = submit_impl(b, use_hint)) { (void)hipStreamSynchronize(b->stream); return rc; }
+    b->in_flight = true;
+    return AVR_OK;
+}
+
+// Wait for the kernels, then: the coded bytes gathered densely on the device, one D2H copy.
+int avr_batch_wait(avr_batch *b) {
+    if (!b) return fail(AVR_ERR_INVALID, "null batch");
+    if (!b->in_flight) return b->ran ? AVR_OK : fail(AVR_ERR_INVALID, "batch has not been submitted");
+    if (int rc = select_device(b->device)) return rc;
+    b->in_flight = false;
+    const size_t n = b->n_bins.size();
+    if (n == 0) { b->ran = true; return AVR_OK; }
+    const uint32_t n32 = uint32_t(n);
+    hipStream_t s = b->stream;
+    int rc;
     AVR_HIP(hipStreamSynchronize(s));
+    b->info[0] = uint32_t(b->last_path); b->info[1] = b->info[2] = b->info[3] = 0;
+    if (b->kind == AVR_KIND_CABAC) {
+        // The run was sized by a guess of the context count.  The one-lane-per-slice kernel is exact whatever the
+        // guess; the intra-slice parallel kernels only if the batch needs no more rows than guessed: else once more,
+        // asking the device this time.
+        b->info[1] = b->hint_used; b->info[3] = 0;
+        if (b->hint_used && b->last_path == 1 && b->h_ndense.p[0] > b->hint_used) {
+            if ((rc = submit_impl(b, false))) { (void)hipStreamSynchronize(s); return rc; }
+            AVR_HIP(hipStreamSynchronize(s));
+            b->info[3] = 1;
+        }
+        b->info[2] = b->h_ndense.p[0];
+        const uint32_t seen = b->h_ndense.p[0];
+        if (seen) b->dense_hint = std::min<uint32_t>(uint32_t(b->n_states), seen + 8);   // a little room: the next batch of a stream rarely needs more
+    }
     for (size_t i = 0; i < n; i++) {
-        const uint64_t cap = out_off[i + 1] - out_off[i];
+        const uint64_t cap = b->out_off[i + 1] - b->out_off[i];
         b->dense_off[i + 1] = b->dense_off[i] + std::min<uint64_t>(b->h_out_len.p[i], cap);
     }
     const uint64_t dense_total = b->dense_off.back();
     if ((rc = b->d_dense.reserve(dense_total + 1)) || (rc = b->h_out.reserve(dense_total + 1))) return rc;
-    AVR_HIP(hipMemcpyAsync(b->d_dense_off.p, b->dense_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    b->plan_used = 0;                                            // the run's plan arrays are consumed: the arena is free again
+    AVR_STAGE(b->d_dense_off.p, b->dense_off.data(), n + 1);
     AVR_HIP(avr::launch_compact(s, b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_dense_off.p, n32, b->d_dense.p));
     if (dense_total) AVR_HIP(hipMemcpyAsync(b->h_out.p, b->d_dense.p, dense_total, hipMemcpyDeviceToHost, s));
     AVR_HIP(hipEventRecord(b->ev[4], s));
@@ -454,6 +538,13 @@ static int fetch_output(avr_batch *b, const std::vector<uint64_t> &out_off, uint
     for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&b->ms[i], b->ev[i], b->ev[i + 1]);
     b->ran = true;                                               // only now: the getters hand out h_out / h_status
     return AVR_OK;
+}
+
+int avr_batch_run(avr_batch *b) {
+    if (!b) return fail(AVR_ERR_INVALID, "null batch");
+    if (b->ran) return fail(AVR_ERR_INVALID, "batch already ran");
+    if (int rc = avr_batch_submit(b)) return rc;
+    return avr_batch_wait(b);
 }
 
 int avr_batch_get(avr_batch *b, size_t slice, const uint8_t **bytes, size_t *len, int *status) {
@@ -471,6 +562,12 @@ int avr_batch_get_states(avr_batch *b, size_t slice, const uint8_t **states, siz
     if (slice >= b->n_bins.size()) return fail(AVR_ERR_INVALID, "slice %zu out of range", slice);
     if (states) *states = b->h_final.p + slice * b->n_states;
     if (n_states) *n_states = b->n_states;
+    return AVR_OK;
+}
+
+int avr_batch_run_info(avr_batch *b, uint32_t info[4]) {
+    if (!b || !b->ran || !info) return fail(AVR_ERR_INVALID, "batch has not run");
+    memcpy(info, b->info, sizeof b->info);
     return AVR_OK;
 }
 

@@ -17,11 +17,22 @@
 
 namespace avr {
 
+// How many LDS rows the renumbered contexts of a batch need is known on the device after the census; the launches
+// that follow are sized by it, which costs the host one 4-byte round trip per call.  A caller that has a good guess
+// (the batch API: the count of its previous batch) passes it here: the launches are sized by `rows`, nothing waits,
+// and the true count is copied to *host_count (pinned) behind the kernels for the caller to check afterwards:
+//   * the one-lane-per-slice kernel is exact whatever the guess: contexts beyond `rows` are handed back like
+//     contexts the sampled census missed;
+//   * the intra-slice parallel kernels are exact iff *host_count <= rows: otherwise the caller runs the call again
+//     without a hint (they never fault: a dense id >= rows is treated as "no context").
+struct DenseHint { uint32_t rows; uint32_t *host_count; };
+
 hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
                                const uint8_t *init_states, uint32_t n_states, uint8_t *out,
                                const uint64_t *out_off, uint32_t *out_len, int32_t *status,
-                               uint8_t *final_states, int32_t want_status = AVR_SLICE_OK, bool dense = true);
+                               uint8_t *final_states, int32_t want_status = AVR_SLICE_OK, bool dense = true,
+                               const DenseHint *hint = nullptr);
 // used (1024 bits) -> table[caller's context number] = dense id (0xffff: unused), index[dense id] = caller's number, *n_dense
 hipError_t launch_densemap(hipStream_t s, const uint32_t *used, uint16_t *table, uint16_t *index, uint32_t *n_dense);
 hipError_t launch_range_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,
@@ -49,7 +60,7 @@ size_t k1p_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_p
 hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
                       uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
                       void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
-                      uint8_t *final_states);
+                      uint8_t *final_states, const DenseHint *hint = nullptr);
 size_t k1p_resolve_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl);
 hipError_t launch_k1p_resolve(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
                               uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,

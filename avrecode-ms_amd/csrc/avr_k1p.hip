@@ -145,6 +145,7 @@ __global__ __launch_bounds__(1024) void k_k1p_densemap(const uint32_t *used, uin
     const uint32_t id = sc[k] - bit;
     table[k] = bit ? uint16_t(id) : uint16_t(kNotUsed);
     if (bit) index[id] = uint16_t(k);
+    if (k >= sc[1023]) index[k] = uint16_t(kNotUsed);            // rows a launch sized by a guess has beyond the count: no context
     if (k == 1023) *n_dense = sc[1023];
 }
 
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
     const uint32_t s = wave / groups, k = (wave - s * groups) + lane * groups, nk = p.n_states;
     if (lane >= chain_lanes || s >= n_slices || status[s] != AVR_SLICE_OK || k >= nk) return;
     const uint32_t col = p.index[k], row4 = ((nk + 3) >> 2) << 2;
+    if (col >= p.ns_full) return;                                // a row beyond the batch's contexts (launch sized by a guess)
     uint32_t st = init_states[size_t(s) * p.ns_full + col] & 127u;
     const uint32_t c0 = p.chunk_base[s], nc = (p.n_bins[s] + kChunk - 1) / kChunk;
     const uint16_t *le = lend + size_t(c0) * nk + k;             // end[k] of the chunk being requested (four ahead)
@@ -861,7 +863,7 @@ static inline ResolveLayout resolve_layout(size_t n_slices, uint32_t ns, const a
 
 static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const uint8_t *init_states,
                                  const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, int32_t *status, uint8_t *final_states,
-                                 uint32_t max_stretch, const Stretch **stretch_out) {
+                                 uint32_t max_stretch, const Stretch **stretch_out, const DenseHint *hint = nullptr) {
     const uint32_t ns = p.ns_full;
     const ResolveLayout L = resolve_layout(n_slices, ns, pl);
     uint32_t *lbits = reinterpret_cast<uint32_t *>(w + L.lbits);
@@ -883,8 +885,14 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
     hipLaunchKernelGGL(k_k1p_densemap, dim3(1), dim3(1024), 0, s, used, table, index, n_dense);
     hipLaunchKernelGGL(k_k1p_tn, dim3((kTnBytes + 255) / 256), dim3(256), 0, s, tn);
     uint32_t n_states = 0;
-    if ((e = hipMemcpyAsync(&n_states, n_dense, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    if (hint && hint->rows) {                                    // sized by the caller's guess, checked by the caller afterwards (DenseHint)
+        n_states = hint->rows < ns ? hint->rows : ns;
+        if (hint->host_count && (e = hipMemcpyAsync(hint->host_count, n_dense, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    } else {
+        if ((e = hipMemcpyAsync(&n_states, n_dense, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        if (hint && hint->host_count) *hint->host_count = n_states;
+    }
     p.n_states = n_states;
     {
         // the waves of a workgroup share the renumbering table; each has its own counters and bit strings
@@ -971,14 +979,14 @@ size_t k1p_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_p
 hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
                       uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
                       void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
-                      uint8_t *final_states) {
+                      uint8_t *final_states, const DenseHint *hint) {
     if (n_slices == 0) return hipSuccess;
     uint8_t *w = static_cast<uint8_t *>(workspace);
     uint8_t *res = w;                                        w += up256(pl->res_total + 32);
     const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
                  pl->dig_off, 0, n_states, nullptr, nullptr};
     const Stretch *st = nullptr;
-    hipError_t e = launch_resolve(s, p, n_slices, init_states, pl, w, res, status, final_states, kMaxStretch, &st);
+    hipError_t e = launch_resolve(s, p, n_slices, init_states, pl, w, res, status, final_states, kMaxStretch, &st, hint);
     if (e != hipSuccess) return e;
     w += resolve_ws_bytes(n_slices, n_states, pl);
     e = launch_code(s, p, n_slices, pl, w, res, kMaxStretch, out, out_off, out_len, status, st);

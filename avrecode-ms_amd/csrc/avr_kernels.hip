@@ -152,7 +152,10 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
             for (uint32_t b = 0; b < 4; b++) {
                 const uint32_t k = 4 * k4 + b;
                 uint32_t sv = k == n_rows ? 128u : k == n_rows + 1 ? 130u : k == n_rows + 3 ? 134u : 132u;   // the pseudo contexts (and padding)
-                if (k < n_rows && active) sv = src[index ? uint32_t(index[k]) : k];
+                if (k < n_rows && active) {
+                    const uint32_t col = index ? uint32_t(index[k]) : k;        // 0xffff: a row beyond the batch's contexts (launch sized by a guess)
+                    sv = col < n_states ? src[col] : 0u;
+                }
                 v |= sv << (8 * b);
             }
             st32[k4 * 64 + lane] = v;
@@ -205,7 +208,10 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
         if (final_states && active && st != AVR_SLICE_RETRY_SERIAL) {                            // final_states starts out as a copy of init_states when a renumbering is in use
             uint8_t *dst = final_states + size_t(slice) * n_states;
             const uint8_t *col = reinterpret_cast<const uint8_t *>(st32) + lane * 4;
-            for (uint32_t k = 0; k < n_rows; k++) dst[index ? uint32_t(index[k]) : k] = col[((k >> 2) << 8) + (k & 3)];
+            for (uint32_t k = 0; k < n_rows; k++) {
+                const uint32_t c = index ? uint32_t(index[k]) : k;
+                if (c < n_states) dst[c] = col[((k >> 2) << 8) + (k & 3)];
+            }
         }
     }
 }
@@ -563,7 +569,7 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
                                const uint8_t *init_states, uint32_t n_states, uint8_t *out,
                                const uint64_t *out_off, uint32_t *out_len, int32_t *status,
-                               uint8_t *final_states, int32_t want_status, bool dense) {
+                               uint8_t *final_states, int32_t want_status, bool dense, const DenseHint *hint) {
     if (n_slices == 0) return hipSuccess;
     hipError_t err;
     uint32_t n_rows = n_states;
@@ -583,8 +589,15 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
         else hipLaunchKernelGGL(k_k1_census<false>, cgrid, dim3(256), 0, s, recs, off, n_bins, order, n_slices, used, stride);
         if ((err = launch_densemap(s, used, t, t + 1024, used + 32)) != hipSuccess) return err;
         uint32_t nd = 0;
-        if ((err = hipMemcpyAsync(&nd, used + 32, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return err;
-        if ((err = hipStreamSynchronize(s)) != hipSuccess) return err;
+        if (hint && hint->rows) {                                // sized by the caller's guess: nothing waits (see DenseHint)
+            nd = hint->rows;
+            retry = true;
+            if (hint->host_count && (err = hipMemcpyAsync(hint->host_count, used + 32, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return err;
+        } else {
+            if ((err = hipMemcpyAsync(&nd, used + 32, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return err;
+            if ((err = hipStreamSynchronize(s)) != hipSuccess) return err;
+            if (hint && hint->host_count) *hint->host_count = nd;
+        }
         // a selector >= n_states is not a context of the slice even if it occurs: the table only serves selectors < n_states
         // (k_pack_tiles has flagged such records; the kernel sends them to the no-op row either way, see sel_off)
         n_rows = nd < n_states ? nd : n_states;

@@ -274,8 +274,9 @@ def main():
                        "layout": "slice-major" if path == "chunked" else "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("K1p: k_k1p_{hist,densemap,scan,scatter,spec,link,chain,entry,replay,b1,b2,zero,c,d} (one step = "
-                                    "all of them; largest: k_k1p_scatter)" if path == "chunked" else "k_cabac_encode<tiled>")
+                         "kernel": ("K1p: k_k1p_{census,densemap,tn,local,ctxchain,replay,b2,zero,c,d} + the idle serial fallback (one step = "
+                                    "all of them; largest: k_k1p_replay)" if path == "chunked" else
+                                    "k_k1_census (1-in-16 sample) + k_k1p_densemap + k_cabac_encode<tiled> + its hand-back launch (one step = all of them)")
                          if kind == avr.KIND_CABAC else "k_range_encode<tiled>",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
                          "bins_per_s": w.total_bins / (kernel_ms * 1e-3)},

@@ -118,12 +118,34 @@ int avr_batch_add_slice_range(avr_batch *b, const uint16_t *recs, size_t n);
  * A batch of few, long slices is coded by the intra-slice parallel kernels (K1p phases B-D), a batch of
  * many short ones by one lane per slice (k_cabac_encode_codes); either way every slice is coded. */
 int avr_batch_add_slice_codes(avr_batch *b, const uint8_t *codes, size_t n);
+/* Zero-copy form of the three calls above: room for a slice of n elements (uint16_t records for AVR_KIND_CABAC /
+ * AVR_KIND_RANGE, uint8_t codes for AVR_KIND_CABAC_CODES) in the batch's pinned staging buffer, which the H2D copy
+ * reads directly; the caller writes exactly n elements to *buffer before avr_batch_submit / avr_batch_run (the padding
+ * after them is already in place).  init_states / n_states as for avr_batch_add_slice_cabac (copied now), ignored
+ * for the other kinds.  A recorder that appends here saves one pass over its records.  Returns the slice index. */
+int avr_batch_reserve_slice(avr_batch *b, int kind, size_t n, const uint8_t *init_states, size_t n_states, void **buffer);
 
+/* avr_batch_run = avr_batch_submit + avr_batch_wait.
+ * avr_batch_submit enqueues the whole run on the batch's own stream -- H2D from pinned memory, the kernels, the
+ * lengths on their way back -- and returns without waiting for the device (the first CABAC-record run of a batch
+ * object waits once for a 4-byte context count; later runs are sized by that count and checked in avr_batch_wait).
+ * avr_batch_wait blocks until the results are in host memory.  Between the two calls the batch must not be
+ * touched (add / reset / get fail with AVR_ERR_INVALID).  Two or three batch objects used in turn keep the copy
+ * engines and the kernels of consecutive batches overlapped:
+ *     submit(b[0]);  for (i = 1; ; i++) { fill(b[i % 2]); submit(b[i % 2]); wait(b[(i - 1) % 2]); consume; reset; }
+ * After avr_batch_wait a batch may be submitted again as it is (same slices, coded anew). */
+int avr_batch_submit(avr_batch *b);
+int avr_batch_wait(avr_batch *b);
 int avr_batch_run(avr_batch *b);
 
 int avr_batch_get(avr_batch *b, size_t slice, const uint8_t **bytes, size_t *len, int *status);
 /* K1 only: the slice's state bytes after its last bin (what cabac_code.h:43-47 leaves in *state). */
 int avr_batch_get_states(avr_batch *b, size_t slice, const uint8_t **states, size_t *n_states);
+/* How the last run went: [0] 1 = intra-slice parallel kernels, 0 = one lane per slice; [1] context rows the kernels
+ * were sized by from the previous run's count (0: the run asked the device and waited); [2] contexts the batch uses
+ * (as the census saw them: a sample on the one-lane-per-slice path); [3] 1 = avr_batch_wait found the guess too
+ * small and ran the batch again.  CABAC-record batches; zeros otherwise. */
+int avr_batch_run_info(avr_batch *b, uint32_t info[4]);
 /* milliseconds of the last run: [0] H2D, [1] pack kernel, [2] encode kernel, [3] D2H */
 int avr_batch_timings(avr_batch *b, float ms[4]);
 

@@ -286,3 +286,78 @@ def test_one_batch_over_several_devices(avr, oracle):
         m.run()
         for i, r in enumerate(rr):
             assert m.get(i) == oracle.range_encode(r), f"range slice {i}"
+
+
+def test_batch_submit_wait_in_turn(avr, oracle):
+    """Two batch objects used in turn (avr_batch_submit / avr_batch_wait): every round's bytes, final states and
+    statuses equal the oracle's.  The rounds are chosen to walk the size guess through its cases: the first run of an
+    object asks the device for the context count; later runs are sized by the previous count; round 3 uses MORE
+    contexts than any before (one-lane-per-slice path: the extra contexts are handed back to the second launch);
+    rounds 4 to 6 are few long slices (intra-slice parallel path), 6 with more contexts than its object has seen (the
+    guess is too small: avr_batch_wait runs the batch again).  Slices go in through the zero-copy call on odd rounds."""
+    rng = np.random.default_rng(2024)
+    def round_slices(k):
+        if k < 4:
+            n_ctx = [40, 40, 40, 400][k]
+            return [oracle_lib.random_cabac_stream(rng, int(rng.integers(0, 1500)), n_ctx) for _ in range(150)], 460
+        n_ctx = 30 if k == 4 else 200
+        return [oracle_lib.random_cabac_stream(rng, 20000 + 1000 * i, n_ctx) for i in range(4)], 460
+    rounds = []
+    for k in range(7):                                 # round 6: long slices, 200 contexts, on the object whose last count was 30
+        sl, ns = round_slices(min(k, 5))
+        sl = [(r, np.concatenate([s, np.zeros(ns - len(s), np.uint8)])) for r, s in sl]
+        rounds.append(sl)
+    bs = [avr.Batch(0, 200, 200000), avr.Batch(0, 200, 200000)]
+    try:
+        def fill(b, sl, zero_copy):
+            b.reset()
+            for r, s in sl:
+                if zero_copy:
+                    _, view = b.reserve(avr.KIND_CABAC, len(r), s)
+                    view[:] = r
+                else:
+                    b.add_slice_cabac(r, s)
+        infos = {}
+        def check(b, sl, k):
+            infos[k] = b.run_info()
+            for i, (r, s) in enumerate(sl):
+                data, status = b.get(i)
+                assert (data, b.get_states(i), status) == oracle.cabac_encode(r, s), f"round {k} slice {i}"
+        fill(bs[0], rounds[0], False)
+        bs[0].submit()
+        with pytest.raises(avr.AvrError):
+            bs[0].get(0)                          # in flight: nothing to hand out yet
+        with pytest.raises(avr.AvrError):
+            bs[0].reset()
+        for k in range(1, len(rounds)):
+            fill(bs[k % 2], rounds[k], k % 2 == 1)
+            bs[k % 2].submit()
+            bs[(k - 1) % 2].wait()
+            check(bs[(k - 1) % 2], rounds[k - 1], k - 1)
+        bs[(len(rounds) - 1) % 2].wait()
+        check(bs[(len(rounds) - 1) % 2], rounds[-1], len(rounds) - 1)
+        assert [infos[k]["chunked"] for k in range(7)] == [0, 0, 0, 0, 1, 1, 1]
+        assert infos[0]["rows_guessed"] == 0 and infos[1]["rows_guessed"] == 0          # first run of each object asks the device
+        assert infos[2]["rows_guessed"] > 0 and infos[3]["rows_guessed"] < 100 < infos[3]["contexts_seen"]   # handed back, not run again
+        assert [infos[k]["ran_again"] for k in range(7)] == [0, 0, 0, 0, 0, 0, 1]
+        # the same batch again, as it is
+        b = bs[(len(rounds) - 1) % 2]
+        b.submit()
+        b.wait()
+        check(b, rounds[-1], "again")
+    finally:
+        for b in bs:
+            b.close()
+
+
+def test_batch_submit_wait_codes_and_range(avr, oracle):
+    rng = np.random.default_rng(5)
+    ranges = [oracle_lib.random_range_stream(rng, int(rng.integers(0, 1500))) for _ in range(70)]
+    with avr.Batch(0, 100, 200000) as b:
+        for r in ranges:
+            _, view = b.reserve(avr.KIND_RANGE, len(r))
+            view[:] = r
+        b.submit()
+        b.wait()
+        for i, r in enumerate(ranges):
+            assert b.get(i) == oracle.range_encode(r), f"K2 slice {i}"

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the batch API (host records in, host bytes out) -- never bench.py's `value`.
 
-    python tools/e2e_batch.py [--workload 2] [--slices 128]
+    python tools/e2e_batch.py [--workload 2] [--slices 128]          (E2E_OBJECTS=3, E2E_ROUNDS=30, E2E_CODES=1)
+
+Batches are submitted in turn over a few batch objects (avr_batch_submit / avr_batch_wait) and, for comparison, one at
+a time (avr_batch_run); outputs are checked against each other.
 """
 import argparse
 import ctypes
@@ -47,35 +50,59 @@ def resolve(r, states):
     return out
 
 
-with avr.Batch(0, n, int(nb.sum()) + 8) as b:
-    for rep in range(3):
-        b.reset()
-        t0 = time.perf_counter()
-        for i in range(n):
-            b.add_slice_cabac(recs[int(off[i]):int(off[i]) + int(nb[i])], st[i * cfg.n_states:(i + 1) * cfg.n_states])
-        t1 = time.perf_counter()
-        b.run()
-        t2 = time.perf_counter()
-        out_bytes = sum(len(b.get(i)[0]) for i in range(n))
-        t = b.timings()
-        print(f"rep {rep}: {n} slices, {int(nb.sum())} bins, {out_bytes} H.264 bytes | add (host memcpy) {1e3*(t1-t0):.1f} ms, "
-              f"run {1e3*(t2-t1):.1f} ms [h2d {t['h2d_ms']:.2f} plan/pack {t['pack_ms']:.2f} encode {t['encode_ms']:.2f} d2h {t['d2h_ms']:.2f}] "
-              f"-> {out_bytes/(t2-t1)/1e9:.2f} GB/s of H.264 through avr_batch_run")
+def pipeline(batches, rounds, label, out_bytes):
+    """submit / wait over the batch objects in turn (each holds its slices in pinned memory already, as a recorder that
+    appends through avr_batch_reserve_slice leaves them): H2D of one batch under the kernels and D2H of the others."""
+    for b in batches:                                      # first run of an object: asks the device for the context count
+        b.submit(); b.wait()
+    k = len(batches)
+    t0 = time.perf_counter()
+    for i in range(rounds):
+        if i >= k:
+            batches[i % k].wait()
+        batches[i % k].submit()
+    for i in range(rounds, rounds + k):
+        batches[i % k].wait()
+    t = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for i in range(rounds):
+        batches[i % k].submit(); batches[i % k].wait()
+    ts = time.perf_counter() - t1
+    print(f"{label}: {rounds} batches of {n} slices over {k} batch objects | in turn {1e3*t/rounds:.2f} ms per batch = "
+          f"{rounds*out_bytes/t/1e9:.2f} GB/s of H.264 | one at a time {1e3*ts/rounds:.2f} ms = {rounds*out_bytes/ts/1e9:.2f} GB/s | "
+          f"last run: {batches[0].run_info()} {batches[0].timings()}")
 
-    if os.environ.get("E2E_CODES", "1") != "0":
-        m = min(n, 8)                                      # resolving in Python is slow: a few slices, repeated
-        codes = [resolve(recs[int(off[i]):int(off[i]) + int(nb[i])], st[i * cfg.n_states:(i + 1) * cfg.n_states]) for i in range(m)]
-        want = [b.get(i)[0] for i in range(m)]
-        with avr.Batch(0, n, int(nb[:m].max()) * n + 64 * n) as bc:
-            for rep in range(3):
-                bc.reset()
-                for i in range(n):
-                    bc.add_codes(codes[i % m])
-                t1 = time.perf_counter()
-                bc.run()
-                t2 = time.perf_counter()
-                out_bytes = sum(len(bc.get(i)[0]) for i in range(n))
-                t = bc.timings()
-                assert all(bc.get(i)[0] == want[i] for i in range(m))
-                print(f"codes rep {rep}: {n} slices | run {1e3*(t2-t1):.1f} ms [h2d {t['h2d_ms']:.2f} encode {t['encode_ms']:.2f} "
-                      f"d2h {t['d2h_ms']:.2f}] -> {out_bytes/(t2-t1)/1e9:.2f} GB/s of H.264 through avr_batch_run from resolved codes")
+
+K = int(os.environ.get("E2E_OBJECTS", "3"))
+ROUNDS = int(os.environ.get("E2E_ROUNDS", "30"))
+bs = [avr.Batch(0, n, int(nb.sum()) + 8) for _ in range(K)]
+t0 = time.perf_counter()
+for b in bs:
+    for i in range(n):
+        b.add_slice_cabac(recs[int(off[i]):int(off[i]) + int(nb[i])], st[i * cfg.n_states:(i + 1) * cfg.n_states])
+t1 = time.perf_counter()
+print(f"host fill (memcpy into pinned memory, one thread): {K * recs.nbytes / (t1 - t0) / 1e9:.1f} GB/s of records")
+bs[0].run()
+want_all = [bs[0].get(i)[0] for i in range(n)]
+out_bytes = sum(len(x) for x in want_all)
+bs[0].submit(); bs[0].wait()
+assert all(bs[0].get(i)[0] == want_all[i] for i in range(n))
+pipeline(bs, ROUNDS, "records (2 B per bin)", out_bytes)
+assert all(bs[1].get(i)[0] == want_all[i] for i in range(n))
+for b in bs:
+    b.close()
+
+if os.environ.get("E2E_CODES", "1") != "0":
+    m = min(n, 8)                                          # resolving in Python is slow: a few slices, repeated
+    codes = [resolve(recs[int(off[i]):int(off[i]) + int(nb[i])], st[i * cfg.n_states:(i + 1) * cfg.n_states]) for i in range(m)]
+    bc = [avr.Batch(0, n, int(nb[:m].max()) * n + 64 * n) for _ in range(K)]
+    for b in bc:
+        for i in range(n):
+            b.add_codes(codes[i % m])
+    bc[0].run()
+    assert all(bc[0].get(i)[0] == want_all[i] for i in range(m))
+    out_c = sum(len(bc[0].get(i)[0]) for i in range(n))
+    pipeline(bc, ROUNDS, "resolved codes (1 B per bin)", out_c)
+    assert all(bc[1].get(i)[0] == want_all[i] for i in range(m))
+    for b in bc:
+        b.close()
