@@ -213,14 +213,16 @@ int avr_range_encode_tiles_device(int device, void *stream,
 /* K1, intra-slice parallel form ("K1p", avrecode-ms_amd/csrc/avr_k1p.h): the same bytes as
  * avr_cabac_encode_tiles_device, produced by many lanes per slice -- for batches of few, long
  * slices (a 1-slice-per-frame clip), where one lane per slice leaves the chip idle.  Input is the
- * slice-major layout (padding records must be no-ops).  Context states are resolved by a stable
- * per-slice counting sort over blocks of AVR_SORT_BLOCK_BINS bins; the arithmetic coding runs per
- * chunk of AVR_CHUNK_BINS bins.  The caller supplies the plan (device arrays, n = n_slices):
+ * slice-major layout (padding records must be no-ops).  Everything runs per chunk of AVR_CHUNK_BINS bins:
+ * context states are resolved by a counting sort of each chunk's bins by context (one lane per chunk) and one
+ * state chain per (slice, context) over the sorted chunks; the arithmetic coding per chunk follows.  The call
+ * renumbers the batch onto the contexts it uses by itself (a census pass over blocks of AVR_SORT_BLOCK_BINS
+ * bins, which also validates every record).  The caller supplies the plan (device arrays, n = n_slices):
  *   res_off[i]     byte offset of slice i in the per-bin work arrays, multiple of 16,
  *                  res_off[i+1] - res_off[i] >= roundup16(n_bins[i]) + 16;      res_total = res_off[n]
  *   chunk_base[i]  first global chunk of slice i; it has max(1, ceil(n_bins[i]/AVR_CHUNK_BINS))
  *                  chunks; total_chunks = chunk_base[n]; chunk_slice[c] = slice of global chunk c
- *   blk_base[i], blk_slice[b], total_blocks: the same for blocks of AVR_SORT_BLOCK_BINS bins
+ *   blk_base[i], blk_slice[b], total_blocks: the same for blocks of AVR_SORT_BLOCK_BINS bins (the census grid)
  *   dig_off[i]     first 32-bit digit sum of slice i, dig_off[i+1] - dig_off[i] >= n_bins[i]/2 + 8;
  *                  dig_total = dig_off[n]
  * workspace: avr_cabac_chunked_workspace_bytes(...) bytes of device memory, 256-byte aligned.
@@ -310,8 +312,11 @@ int avr_range_encode_slices_device(int device, void *stream,
  * A context is identified by the offset of its state byte in libavcodec's cabac_state[1024]
  * (recode.cpp:325 keys the model on the address), but a stream uses far fewer of them, and K1
  * keeps 64 lanes x n_states state bytes in LDS per wave: renumbering a batch onto the contexts it
- * uses raises occupancy.  recs is any flat array of CABAC records on the device (a tile buffer or
- * a slice-major buffer), n_records a multiple of 8.
+ * uses raises occupancy.  EVERY K1 ENTRY POINT ABOVE DOES THIS BY ITSELF, inside the call (census kernel,
+ * look-up on load): records and states go in under the caller's numbering and nothing has to be prepared.
+ * The three calls below are the same steps as separate passes, for a caller that wants a renumbered copy of
+ * its records for its own purposes; no path of this library needs them.  recs is any flat array of CABAC
+ * records on the device (a tile buffer or a slice-major buffer), n_records a multiple of 8.
  *   avr_context_census_device   bitmap[32] |= one bit per selector < 1024 that occurs (zero it first)
  *   avr_context_remap_device    selector s < 1024 -> table[s] in place (table: 1024 x uint16 on the device)
  *   avr_states_permute_device   gather (scatter = 0): dst[slice][j] = src[slice][index[j]], j < n_index,
