@@ -147,6 +147,7 @@ struct avr_batch {
     uint32_t dense_hint = 0;                // context rows the previous run of this object needed (0: no run yet)
     uint32_t hint_used = 0;                 // what the run in flight was sized by (0: it asked the device and waited)
     uint32_t info[4] = {0, 0, 0, 0};        // avr_batch_run_info
+    avr_chunk_plan plan{};                  // of the chunked run in flight (device arrays of this batch)
 };
 
 // One plan array to the device through the batch's pinned arena: the copy is asynchronous for real (a copy from
@@ -406,9 +407,9 @@ static int submit_impl(avr_batch *b, bool use_hint) {
 
     hipStream_t s = b->stream;
     b->plan_used = 0;
-    const avr::DenseHint hint{use_hint ? std::min<uint32_t>(b->dense_hint, uint32_t(ns)) : 0u, b->h_ndense.p};
+    const avr::DenseHint hint{use_hint ? std::min<uint32_t>(b->dense_hint, uint32_t(ns)) : 0u, b->h_ndense.p, b->h_ndense.p + 1};
     b->hint_used = hint.rows;
-    b->h_ndense.p[0] = 0;
+    b->h_ndense.p[0] = b->h_ndense.p[1] = 0;
     AVR_HIP(hipEventRecord(b->ev[0], s));
     AVR_HIP(hipMemcpyAsync(b->d_recs.p, b->h_recs.p, total_recs * sizeof(uint16_t), hipMemcpyHostToDevice, s));
     AVR_STAGE(b->d_rec_off.p, b->rec_off.data(), n + 1);
@@ -445,6 +446,7 @@ static int submit_impl(avr_batch *b, bool use_hint) {
                             res_off.back(), dig_off.back(), chunk_base.back(), blk_base.back()};
         const size_t ws = avr::k1p_workspace_bytes(n, uint32_t(ns), &plan);
         if ((rc = b->d_workspace.reserve(ws + 256))) return rc;
+        b->plan = plan;
         AVR_STAGE(b->d_res_off.p, res_off.data(), n + 1);
         AVR_STAGE(b->d_dig_off.p, dig_off.data(), n + 1);
         AVR_STAGE(b->d_chunk_base.p, chunk_base.data(), n + 1);
@@ -518,6 +520,14 @@ int avr_batch_wait(avr_batch *b) {
             if ((rc = submit_impl(b, false))) { (void)hipStreamSynchronize(s); return rc; }
             AVR_HIP(hipStreamSynchronize(s));
             b->info[3] = 1;
+        }
+        if (b->last_path == 1 && b->h_ndense.p[1]) {             // slices with a context the sampled census missed: their second pass
+            uint8_t *wsp = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(b->d_workspace.p) + 255) & ~uintptr_t(255));
+            AVR_HIP(avr::launch_k1p_retry(s, b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, n32, b->d_states.p, uint32_t(b->n_states), &b->plan,
+                                          wsp, b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p, b->d_final.p));
+            if ((rc = enqueue_lengths(b, n32))) return rc;
+            AVR_HIP(hipStreamSynchronize(s));
+            b->info[3] |= 2;
         }
         b->info[2] = b->h_ndense.p[0];
         const uint32_t seen = b->h_ndense.p[0];

@@ -14,6 +14,10 @@
 // transient per-slice status: K1p declined the slice, k_cabac_encode codes it in the same call
 // (never leaves a call: k_cabac_encode / k_cabac_encode_codes replace it with the slice's real status)
 #define AVR_SLICE_RETRY_SERIAL 100
+// transient, inside the intra-slice parallel path only: the slice has a bin in a context the sampled census of the
+// batch missed (it takes the second, fully counted pass); the slice is finished and must be left alone by that pass
+#define AVR_SLICE_RETRY_CENSUS 101
+#define AVR_SLICE_DONE         102
 
 namespace avr {
 
@@ -25,7 +29,10 @@ namespace avr {
 //     contexts the sampled census missed;
 //   * the intra-slice parallel kernels are exact iff *host_count <= rows: otherwise the caller runs the call again
 //     without a hint (they never fault: a dense id >= rows is treated as "no context").
-struct DenseHint { uint32_t rows; uint32_t *host_count; };
+//   * with a guess the intra-slice parallel path also leaves its second pass (slices with a context the sampled
+//     census missed) to the caller: *host_retry (pinned) gets the number of such slices behind the kernels, and a
+//     caller that finds it non-zero calls launch_k1p_retry with the arguments of launch_k1p.
+struct DenseHint { uint32_t rows; uint32_t *host_count; uint32_t *host_retry; };
 
 hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
@@ -61,6 +68,10 @@ hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
                       uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
                       void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
                       uint8_t *final_states, const DenseHint *hint = nullptr);
+hipError_t launch_k1p_retry(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                            uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
+                            void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
+                            uint8_t *final_states);
 size_t k1p_resolve_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl);
 hipError_t launch_k1p_resolve(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
                               uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,

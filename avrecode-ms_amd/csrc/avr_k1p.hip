@@ -76,43 +76,41 @@ constexpr uint32_t kNotUsed = 0xffffu;
 // placement pass of a dozen instructions per bin at full SIMD width, no cross-lane ranking at all -- and
 // the result is tiny: 1024 bits and one 16-bit end position per context per chunk.
 
-// Also the one place every record of this path is examined: a selector that is no context of the
-// slice, bypass or terminate, or a bin after put_terminate(1), flags the slice AVR_SLICE_BAD_RECORD.
-// Contexts are identified under the caller's numbering (the offset of the state byte in cabac_state[],
-// recode.cpp:325: up to 1024, of which a stream touches few); `used` gets one bit per context that occurs.
-__global__ __launch_bounds__(256) void k_k1p_census(Plan p, int32_t *status, uint32_t *used) {
+// Which contexts the batch uses: one bit per context that occurs (`used`), under the caller's numbering (the offset
+// of the state byte in cabac_state[], recode.cpp:325: up to 1024, of which a stream touches few).  `stride` > 1: from
+// a sample -- of each block of kSortBlock bins (64 cache lines of 64 records) the lines l with l % stride ==
+// block % stride, whole lines so that the sample moves 1/stride of the bytes.  The
+// renumbering exists for the LDS footprint of the kernels behind it, so it has to hold the contexts that matter, not
+// all of them: k_k1p_local, which looks every record up anyway, finds the slices with a bin in a context the sample
+// missed (and the records that are no record at all), and those slices take a second pass with a full count.
+// kCensusBlocks blocks to a workgroup, eight threads (one cache line per trip) to a block.
+constexpr uint32_t kCensusBlocks = 32;
+__global__ __launch_bounds__(256) void k_k1p_census(Plan p, uint32_t total_blocks, const int32_t *status, uint32_t *used, uint32_t stride) {
     __shared__ uint8_t flag[AVR_MAX_STATES];
     __shared__ uint32_t bm[32];
-    const uint32_t b = blockIdx.x, s = p.blk_slice[b], nk = p.ns_full;
     for (uint32_t k = threadIdx.x; k < AVR_MAX_STATES / 4; k += 256) reinterpret_cast<uint32_t *>(flag)[k] = 0;
     if (threadIdx.x < 32) bm[threadIdx.x] = 0;
     __syncthreads();
-    if (status[s] == AVR_SLICE_OK) {
-        const uint32_t n = p.n_bins[s], i0 = (b - p.blk_base[s]) * kSortBlock;
-        const uint32_t i1 = i0 + kSortBlock < n ? i0 + kSortBlock : n;
-        const uint16_t *r = p.recs + p.rec_off[s];
-        // 8 records (one 16-byte chunk) per thread per trip; a slice's padding records are no-ops,
-        // and i0 is a multiple of 8, so whole chunks can be read up to the padded end
-        // Records that are no context bin: bypass (selector 1024) and terminate (1025) are the values
-        // 2048..2051; anything else is bad, and so is put_terminate(1) = 2051 anywhere but last.
-        uint32_t worst = 0;                                      // max over non-context records of (record - 2048), wrapping
-        for (uint32_t i = i0 + threadIdx.x * 8; i < i1; i += 256 * 8) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(r + i);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t b = blockIdx.x * kCensusBlocks + (threadIdx.x >> 3), t = threadIdx.x & 7, nk = p.ns_full;
+    if (b < total_blocks) {
+        const uint32_t s = p.blk_slice[b];
+        if (status[s] == AVR_SLICE_OK) {
+            const uint32_t n = p.n_bins[s], i0 = (b - p.blk_base[s]) * kSortBlock;
+            const uint32_t i1 = i0 + kSortBlock < n ? i0 + kSortBlock : n;
+            const uint16_t *r = p.recs + p.rec_off[s];
+            // a slice's padding records are no-ops and i0 is a multiple of 8: whole groups can be read up to the padded end
+            for (uint32_t l = b % stride; l < kSortBlock / 64; l += stride) {
+                const uint32_t i = i0 + l * 64 + t * 8;
+                if (i >= i1) continue;
+                const uint4 v = *reinterpret_cast<const uint4 *>(r + i);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) {
-                const uint32_t rec = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu, sel = rec >> 1;   // sel keeps bits 12..15: a set one is bad too
-                if (i + j < i1) {
-                    if (sel < nk) flag[sel] = 1;                 // plain store: every writer writes the same value
-                    else {
-                        const uint32_t t = rec - 2048u + (i + j + 1 == n ? 0u : (rec == 2051u ? 4u : 0u));
-                        worst = worst > t ? worst : t;
-                    }
+                for (uint32_t j = 0; j < 8; j++) {
+                    const uint32_t sel = ((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu) >> 1;       // keeps bits 12..15: no context then
+                    if (i + j < i1 && sel < nk) flag[sel] = 1;   // plain store: every writer writes the same value
                 }
             }
         }
-        const bool bad = worst > 3u;
-        if (bad) status[s] = AVR_SLICE_BAD_RECORD;
     }
     __syncthreads();
     {
@@ -127,6 +125,15 @@ __global__ __launch_bounds__(256) void k_k1p_census(Plan p, int32_t *status, uin
         const uint32_t mine = bm[threadIdx.x];
         if (mine & ~__hip_atomic_load(&used[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&used[threadIdx.x], mine);
     }
+}
+
+// OK <-> DONE around the second pass: a -> b and c -> d in one sweep
+__global__ __launch_bounds__(256) void k_k1p_swap(int32_t *status, uint32_t n, int32_t a, int32_t b, int32_t c, int32_t d) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t v = status[i];
+    if (v == a) status[i] = b;
+    else if (v == c) status[i] = d;
 }
 
 // used (1024 bits) -> table[caller's number] = dense id, index[dense id] = caller's number, *n_dense.
@@ -180,32 +187,44 @@ __global__ __launch_bounds__(256) void k_k1p_tn(uint8_t *tn) {
 // trips (the compiler must keep them in order: two bins of a group may hit the same counter).
 // Row j of `cnt` and row j of `bits` are 64 lanes wide: the data-dependent accesses never conflict across
 // lanes.  What a record's 11-bit selector means is one look-up: sel_tab[selector] = byte offset of the
-// counter row | 16 for the high half.  A bin that is no context bin (bypass, terminate, padding, a context
-// the batch does not use) counts into a spare row whose positions start at 1024, i.e. land in a spare row
-// of `bits`: no branch on the bin kind anywhere.
-__global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks, const int32_t *status, uint32_t *lbits,
-                                                   uint16_t *lend) {
-    extern __shared__ uint32_t local_lds[];                      // per wave: bits[33][64], then cnt[(nk + 2) / 2][64] (two 16-bit counters each)
+// counter row | 16 for the high half.  Rows past the contexts: nk = terminate bins (sorted like a context: their
+// values end up side by side behind the last context's), nk + 1 = bypass and padding, nk + 2 = a context of the
+// slice that has no dense id (the sampled census missed it), nk + 3 = no selector of the slice at all.  The last
+// three count from position 1024, i.e. land in a spare row of `bits`: no branch on the bin kind anywhere.
+//
+// This is also where every record of the path is examined (the census only samples).  A lane flags its slice
+//   AVR_SLICE_BAD_RECORD    if row nk + 3 is not empty, a record has a bit above its selector set, or a
+//                           put_terminate(1) is anywhere but last (the terminate row holds a 1 that is not the
+//                           slice's last bin: a handful of bits to look at per chunk);
+//   AVR_SLICE_RETRY_CENSUS  (internal) if row nk + 2 is not empty, counting such slices in *n_retry.
+__global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks, int32_t *status, uint32_t *lbits,
+                                                   uint16_t *lend, uint32_t *n_retry) {
+    extern __shared__ uint32_t local_lds[];                      // per wave: bits[33][64], then cnt[(nk + 5) / 2][64] (two 16-bit counters each)
     __shared__ uint32_t sel_tab[2048];
     const uint32_t nk = p.n_states, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t cnt_rows = (nk + 2) / 2;                      // contexts 0 .. nk-1 and the spare row nk
+    const uint32_t cnt_rows = (nk + 5) / 2;                      // contexts 0 .. nk-1 and the rows nk .. nk+3
     const uint32_t wave_dwords = (33 + cnt_rows) * 64;
     uint32_t *bits = local_lds + wv * wave_dwords;
     uint32_t *cnt = bits + 33 * 64;
     for (uint32_t sel = threadIdx.x; sel < 2048; sel += blockDim.x) {
-        const uint32_t d = sel < 1024u ? uint32_t(p.table[sel]) : kNotUsed;
-        const uint32_t k = d < nk ? d : nk;
+        uint32_t k;
+        if (sel < 1024u) {
+            const uint32_t d = p.table[sel];
+            k = d < nk ? d : sel < p.ns_full ? nk + 2 : nk + 3;
+        } else k = sel == AVR_SEL_TERMINATE ? nk : (sel == AVR_SEL_BYPASS || sel == (AVR_NOP_CABAC >> 1)) ? nk + 1 : nk + 3;
         sel_tab[sel] = (k >> 1) * 256u | (k & 1u) * 16u;
     }
     for (uint32_t i = lane; i < wave_dwords; i += 64) bits[i] = 0;
     __syncthreads();
     const uint32_t gc0 = (blockIdx.x * (blockDim.x >> 6) + wv) * 64, gc = gc0 + lane;
-    uint32_t i0 = 0, i1 = 0;
+    uint32_t i0 = 0, i1 = 0, n = 0, s = 0;
+    bool mine = false;                                           // the lane has a chunk of a live slice
     const uint16_t *r = p.recs;
     if (gc < total_chunks) {
-        const uint32_t s = p.chunk_slice[gc];
+        s = p.chunk_slice[gc];
         if (status[s] == AVR_SLICE_OK) {
-            const uint32_t n = p.n_bins[s];
+            mine = true;
+            n = p.n_bins[s];
             i0 = (gc - p.chunk_base[s]) * kChunk;
             i1 = i0 + kChunk < n ? i0 + kChunk : n;
             if (i0 > i1) i0 = i1;
@@ -229,8 +248,10 @@ __global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks
         }
         for (; i < i1; i += 8) f(*reinterpret_cast<const U4 *>(r + i));
     };
+    uint32_t high = 0;                                           // OR of all records: bits 12..15 must stay clear
     for_groups([&](const U4 &v) {                                // pass 1
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        high |= (w[0] | w[1]) | (w[2] | w[3]);
         uint32_t e[8];
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++) e[j] = sel_tab[((w[j >> 1] >> ((j & 1) * 16)) >> 1) & 0x7ffu];
@@ -239,13 +260,18 @@ __global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks
             __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(cnt_b + (e[j] & ~255u)), 1u << (e[j] & 31u), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
     });
+    auto count_of = [&](uint32_t k) { return (my_cnt[64 * (k >> 1)] >> (16 * (k & 1u))) & 0xffffu; };
+    const uint32_t n_term = count_of(nk), n_missed = count_of(nk + 2), n_invalid = count_of(nk + 3) | (high & 0xf000f000u);
+    uint32_t term_at = 0;                                        // where the terminate row starts
     {
-        uint32_t run = 0;                                        // exclusive prefix; the spare row starts at 1024
+        uint32_t run = 0;                                        // exclusive prefix over the contexts and the terminate row; the rest starts at 1024
         for (uint32_t j = 0; j < cnt_rows; j++) {
             const uint32_t c = my_cnt[64 * j], c0 = c & 0xffffu, c1 = c >> 16;
-            const uint32_t s0 = 2 * j < nk ? run : 1024u, s1 = 2 * j + 1 < nk ? run + c0 : 1024u;
+            const uint32_t s0 = 2 * j <= nk ? run : 1024u, s1 = 2 * j + 1 <= nk ? run + c0 : 1024u;
+            if (2 * j == nk) term_at = s0;
+            if (2 * j + 1 == nk) term_at = s1;
             my_cnt[64 * j] = s0 | s1 << 16;
-            run += (2 * j < nk ? c0 : 0u) + (2 * j + 1 < nk ? c1 : 0u);
+            run += (2 * j <= nk ? c0 : 0u) + (2 * j + 1 <= nk ? c1 : 0u);
         }
     }
     for_groups([&](const U4 &v) {                                // pass 2
@@ -266,6 +292,19 @@ __global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks
                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     });
+    if (mine) {
+        uint32_t ones = 0;                                       // put_terminate(1) among the chunk's terminate bins
+        for (uint32_t pos = term_at; pos < term_at + n_term;) {
+            const uint32_t lo = pos & 31u, take = 32u - lo < term_at + n_term - pos ? 32u - lo : term_at + n_term - pos;
+            const uint32_t mask = (take == 32u ? 0xffffffffu : (1u << take) - 1u) << lo;
+            ones += __popc(my_bits[64 * (pos >> 5)] & mask);
+            pos += take;
+        }
+        constexpr uint32_t kTerm1 = (AVR_SEL_TERMINATE << 1) | 1;
+        const bool bad_term = ones > 1u || (ones == 1u && !(i1 == n && r[n - 1] == kTerm1));   // one 1: it is the last bin iff the last bin is one
+        if (n_invalid || bad_term) status[s] = AVR_SLICE_BAD_RECORD;
+        else if (n_missed && atomicCAS(&status[s], AVR_SLICE_OK, AVR_SLICE_RETRY_CENSUS) == AVR_SLICE_OK) atomicAdd(n_retry, 1u);
+    }
     // out, transposed: flat element f of the wave's 64 rows <-> (chunk f / row, column f % row)
     {
         uint32_t *dst = lbits + size_t(gc0) * 32;
@@ -686,7 +725,7 @@ __global__ __launch_bounds__(256) void k_k1p_d(Plan p, const SliceTotals *tot, c
     __shared__ uint64_t seg_gm[4], seg_pm[4];
     __shared__ uint32_t sh_carry;
     const uint32_t s = blockIdx.x, t = threadIdx.x;
-    if (status[s] != AVR_SLICE_OK) { if (t == 0) out_len[s] = 0; return; }
+    if (status[s] != AVR_SLICE_OK) { if (t == 0 && status[s] != AVR_SLICE_DONE) out_len[s] = 0; return; }   // DONE: coded by the pass before
     const SliceTotals T = tot[s];
     // force_retry_every (test switch AVR_K1P_FORCE_RETRY=n, 0 = off): every n-th slice is handed to the serial
     // kernel as if phase D had met the carry pattern it does not resolve -- the hand-over is then proven on
@@ -863,7 +902,8 @@ static inline ResolveLayout resolve_layout(size_t n_slices, uint32_t ns, const a
 
 static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const uint8_t *init_states,
                                  const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, int32_t *status, uint8_t *final_states,
-                                 uint32_t max_stretch, const Stretch **stretch_out, const DenseHint *hint = nullptr) {
+                                 uint32_t max_stretch, const Stretch **stretch_out, const DenseHint *hint = nullptr,
+                                 uint32_t stride = 1, bool second_pass = false, uint32_t *retry_count = nullptr) {
     const uint32_t ns = p.ns_full;
     const ResolveLayout L = resolve_layout(n_slices, ns, pl);
     uint32_t *lbits = reinterpret_cast<uint32_t *>(w + L.lbits);
@@ -871,17 +911,18 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
     uint8_t *est = w + L.est;
     Stretch *stretch = reinterpret_cast<Stretch *>(w + L.stretch);
     if (stretch_out) *stretch_out = stretch;
-    uint32_t *used = reinterpret_cast<uint32_t *>(w + L.meta);   // [32], then n_dense
-    uint32_t *n_dense = used + 32;
+    uint32_t *used = reinterpret_cast<uint32_t *>(w + L.meta);   // [32], then n_dense, then the number of slices for the second pass
+    uint32_t *n_dense = used + 32, *n_retry = used + 33;
     uint16_t *table = reinterpret_cast<uint16_t *>(w + L.meta + 256), *index = table + 1024;
     uint8_t *tn = w + L.meta + 256 + 4096;
     p.table = table;
     p.index = index;
     hipError_t e;
     if ((e = hipMemsetAsync(used, 0, 256, s)) != hipSuccess) return e;
-    if (final_states && ns && (e = hipMemcpyAsync(final_states, init_states, size_t(n_slices) * ns, hipMemcpyDeviceToDevice, s)) != hipSuccess)
+    if (final_states && ns && !second_pass &&
+        (e = hipMemcpyAsync(final_states, init_states, size_t(n_slices) * ns, hipMemcpyDeviceToDevice, s)) != hipSuccess)
         return e;                                                // contexts without bins keep their state
-    hipLaunchKernelGGL(k_k1p_census, dim3(pl->total_blocks), dim3(256), 0, s, p, status, used);
+    hipLaunchKernelGGL(k_k1p_census, dim3((pl->total_blocks + kCensusBlocks - 1) / kCensusBlocks), dim3(256), 0, s, p, pl->total_blocks, status, used, stride);
     hipLaunchKernelGGL(k_k1p_densemap, dim3(1), dim3(1024), 0, s, used, table, index, n_dense);
     hipLaunchKernelGGL(k_k1p_tn, dim3((kTnBytes + 255) / 256), dim3(256), 0, s, tn);
     uint32_t n_states = 0;
@@ -896,7 +937,7 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
     p.n_states = n_states;
     {
         // the waves of a workgroup share the renumbering table; each has its own counters and bit strings
-        const uint32_t per_wave = (33 + (n_states + 2) / 2) * 64 * 4;
+        const uint32_t per_wave = (33 + (n_states + 5) / 2) * 64 * 4;
         const uint32_t waves = per_wave * 4 <= 60 * 1024 ? 4 : per_wave * 2 <= 60 * 1024 ? 2 : 1;
         const uint32_t lds = waves * per_wave;
         if (lds > 60 * 1024) {
@@ -904,7 +945,18 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(k_k1p_local, dim3((pl->total_chunks + 64 * waves - 1) / (64 * waves)), dim3(64 * waves), lds, s, p,
-                           pl->total_chunks, status, lbits, lend);
+                           pl->total_chunks, status, lbits, lend, n_retry);
+        // How many slices k_k1p_local set aside for the second pass.  Read here, not at the end of the pass: the kernels that
+        // follow are launched while the device is still busy with this one's successors only for a moment, where a wait
+        // after the last kernel would leave the device idle until the caller's next launch.
+        if (stride > 1 && !second_pass) {
+            if (hint && hint->rows && hint->host_retry) {        // the caller looks when it waits (DenseHint)
+                if ((e = hipMemcpyAsync(hint->host_retry, n_retry, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+            } else if (retry_count) {
+                if ((e = hipMemcpyAsync(retry_count, n_retry, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+                if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+            }
+        }
     }
     if (n_states > 0) {
         // lanes per wave: enough waves to hide the chain's latency (about two per SIMD), but not so few lanes per wave that
@@ -976,6 +1028,45 @@ size_t k1p_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_p
     return size_t(up256(pl->res_total + 32) + resolve_ws_bytes(n_slices, n_states, pl)) + k1p_code_workspace_bytes(n_slices, pl);
 }
 
+constexpr uint32_t kK1pCensusStride = 16;
+
+static uint32_t census_stride() {
+    const char *cs = getenv("AVR_CENSUS_STRIDE");
+    return cs && atoi(cs) > 0 ? uint32_t(atoi(cs)) : kK1pCensusStride;
+}
+
+// One pass of the whole path over the slices whose status is AVR_SLICE_OK.
+static hipError_t k1p_pass(hipStream_t s, const Plan &p, uint32_t n_slices, const uint8_t *init_states, uint32_t n_states,
+                           const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, uint8_t *out, const uint64_t *out_off, uint32_t *out_len,
+                           int32_t *status, uint8_t *final_states, const DenseHint *hint, uint32_t stride, bool second_pass,
+                           uint32_t *retry_count) {
+    const Stretch *st = nullptr;
+    hipError_t e = launch_resolve(s, p, n_slices, init_states, pl, w, res, status, final_states, kMaxStretch, &st, hint, stride, second_pass,
+                                  retry_count);
+    if (e != hipSuccess) return e;
+    w += resolve_ws_bytes(n_slices, n_states, pl);
+    e = launch_code(s, p, n_slices, pl, w, res, kMaxStretch, out, out_off, out_len, status, st);
+    if (e != hipSuccess) return e;
+    // slices the scheme declined (status AVR_SLICE_RETRY_SERIAL) are coded by the serial kernel
+    return launch_cabac_encode(false, s, p.recs, p.rec_off, p.n_bins, nullptr, n_slices, init_states, n_states, out, out_off,
+                               out_len, status, nullptr, AVR_SLICE_RETRY_SERIAL);
+}
+
+// The second pass: the slices k_k1p_local set aside (a bin in a context the sampled census missed) once more, with every
+// record counted; the finished ones are parked under AVR_SLICE_DONE meanwhile, which every kernel of the path skips.
+static hipError_t k1p_second_pass(hipStream_t s, const Plan &p, uint32_t n_slices, const uint8_t *init_states, uint32_t n_states,
+                                  const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, uint8_t *out, const uint64_t *out_off,
+                                  uint32_t *out_len, int32_t *status, uint8_t *final_states, bool code) {
+    const dim3 grid((n_slices + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_k1p_swap, grid, block, 0, s, status, n_slices, AVR_SLICE_OK, AVR_SLICE_DONE, AVR_SLICE_RETRY_CENSUS, AVR_SLICE_OK);
+    hipError_t e = code ? k1p_pass(s, p, n_slices, init_states, n_states, pl, w, res, out, out_off, out_len, status, final_states, nullptr, 1,
+                                   true, nullptr)
+                        : launch_resolve(s, p, n_slices, init_states, pl, w, res, status, final_states, kMaxStretch, nullptr, nullptr, 1, true);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_k1p_swap, grid, block, 0, s, status, n_slices, AVR_SLICE_DONE, AVR_SLICE_OK, AVR_SLICE_DONE, AVR_SLICE_OK);
+    return hipGetLastError();
+}
+
 hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
                       uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
                       void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
@@ -985,15 +1076,25 @@ hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
     uint8_t *res = w;                                        w += up256(pl->res_total + 32);
     const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
                  pl->dig_off, 0, n_states, nullptr, nullptr};
-    const Stretch *st = nullptr;
-    hipError_t e = launch_resolve(s, p, n_slices, init_states, pl, w, res, status, final_states, kMaxStretch, &st, hint);
-    if (e != hipSuccess) return e;
-    w += resolve_ws_bytes(n_slices, n_states, pl);
-    e = launch_code(s, p, n_slices, pl, w, res, kMaxStretch, out, out_off, out_len, status, st);
-    if (e != hipSuccess) return e;
-    // slices the scheme declined (status AVR_SLICE_RETRY_SERIAL) are coded by the serial kernel
-    return launch_cabac_encode(false, s, recs, rec_off, n_bins, nullptr, n_slices, init_states, n_states, out, out_off,
-                               out_len, status, nullptr, AVR_SLICE_RETRY_SERIAL);
+    const uint32_t stride = census_stride();
+    uint32_t retry = 0;
+    if (hint && hint->host_retry) *hint->host_retry = 0;
+    hipError_t e = k1p_pass(s, p, n_slices, init_states, n_states, pl, w, res, out, out_off, out_len, status, final_states, hint, stride, false,
+                            &retry);
+    if (e != hipSuccess || !retry) return e;
+    return k1p_second_pass(s, p, n_slices, init_states, n_states, pl, w, res, out, out_off, out_len, status, final_states, true);
+}
+
+hipError_t launch_k1p_retry(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                            uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const avr_chunk_plan *pl,
+                            void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
+                            uint8_t *final_states) {
+    if (n_slices == 0) return hipSuccess;
+    uint8_t *w = static_cast<uint8_t *>(workspace);
+    uint8_t *res = w;                                        w += up256(pl->res_total + 32);
+    const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
+                 pl->dig_off, 0, n_states, nullptr, nullptr};
+    return k1p_second_pass(s, p, n_slices, init_states, n_states, pl, w, res, out, out_off, out_len, status, final_states, true);
 }
 
 // The two stages on their own: phase A into a caller-owned code buffer ...
@@ -1006,8 +1107,13 @@ hipError_t launch_k1p_resolve(hipStream_t s, const uint16_t *recs, const uint64_
     if (n_slices == 0) return hipSuccess;
     const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
                  pl->dig_off, 0, n_states, nullptr, nullptr};
-    return launch_resolve(s, p, n_slices, init_states, pl, static_cast<uint8_t *>(workspace), codes, status, final_states, kMaxStretch,
-                          nullptr);
+    uint8_t *w = static_cast<uint8_t *>(workspace);
+    const uint32_t stride = census_stride();
+    uint32_t retry = 0;
+    hipError_t e = launch_resolve(s, p, n_slices, init_states, pl, w, codes, status, final_states, kMaxStretch, nullptr, nullptr, stride, false,
+                                  &retry);
+    if (e != hipSuccess || !retry) return e;
+    return k1p_second_pass(s, p, n_slices, init_states, n_states, pl, w, codes, nullptr, nullptr, nullptr, status, final_states, false);
 }
 // ... and phases B-D from resolved codes (no stretch is declined for its length here: a stretch without an
 // LPS is simply walked to its end by one lane); a slice phase D hands back is coded by k_cabac_encode_codes

@@ -143,8 +143,9 @@ int avr_batch_get(avr_batch *b, size_t slice, const uint8_t **bytes, size_t *len
 int avr_batch_get_states(avr_batch *b, size_t slice, const uint8_t **states, size_t *n_states);
 /* How the last run went: [0] 1 = intra-slice parallel kernels, 0 = one lane per slice; [1] context rows the kernels
  * were sized by from the previous run's count (0: the run asked the device and waited); [2] contexts the batch uses
- * (as the census saw them: a sample on the one-lane-per-slice path); [3] 1 = avr_batch_wait found the guess too
- * small and ran the batch again.  CABAC-record batches; zeros otherwise. */
+ * (as the sampled census saw them); [3] bit 0 = avr_batch_wait found the guess too small and ran the batch
+ * again, bit 1 = it ran the second pass of the intra-slice parallel path (slices with a bin in a context the sampled
+ * census missed).  CABAC-record batches; zeros otherwise. */
 int avr_batch_run_info(avr_batch *b, uint32_t info[4]);
 /* milliseconds of the last run: [0] H2D, [1] pack kernel, [2] encode kernel, [3] D2H */
 int avr_batch_timings(avr_batch *b, float ms[4]);

@@ -327,3 +327,39 @@ def test_chunked_full_size_configs_3_and_4_sampled(avr, oracle, workload, n_slic
             bins, _ = oracle.spec_cabac_decode(got[s], r, states)
             assert np.array_equal(bins, r & 1)
     assert 0.9 < w.total_bins / (8 * sum(lens)) < 1.8
+
+
+@pytest.mark.parametrize("stride", ["1", "16", "4099"])
+def test_chunked_census_sample_second_pass_and_validation(avr, oracle, stride, monkeypatch):
+    """The intra-slice parallel path renumbers the batch's contexts from a sample of the records; the chunk sort, which
+    looks every record up, sets aside the slices with a bin in a context the sample missed, and those take a second
+    pass with every record counted (stride 4099: the sample is next to nothing, so every slice with a context bin does;
+    stride 1: no sampling).  The same kernel is where records are validated now: a selector the slice does not have, a
+    record with a bit above its selector, put_terminate(1) anywhere but last -- each in the middle of a long slice."""
+    monkeypatch.setenv("AVR_CENSUS_STRIDE", stride)
+    rng = np.random.default_rng(91)
+    ns = 300
+    slices = []
+    for i in range(12):
+        r, s = oracle_lib.random_cabac_stream(rng, 9000 + 2500 * i, 60, terminate=bool(i % 3))
+        slices.append((r, np.concatenate([s, rng.integers(0, 126, ns - 60).astype(np.uint8)])))
+    for i, ctx in ((2, 299), (7, 150), (9, 61)):       # single bins in contexts nobody else uses, far apart
+        slices[i][0][4000 + 777 * i] = np.uint16((ctx << 1) | (i & 1))
+    good = len(slices)
+    def spoiled(at, value):
+        r, s = oracle_lib.random_cabac_stream(rng, 12000, 60)
+        r[at] = np.uint16(value)
+        return r, np.concatenate([s, np.zeros(ns - 60, np.uint8)])
+    slices.append(spoiled(6001, (ns << 1) | 1))            # the first selector past the slice's contexts
+    slices.append(spoiled(11000, (1027 << 1)))             # no selector at all
+    slices.append(spoiled(3, 0x8000 | (5 << 1)))           # a bit above the selector
+    slices.append(spoiled(5000, 1 | (1025 << 1)))          # put_terminate(1) with bins behind it (the stream's own comes last)
+    slices.append(spoiled(11999, 1 | (1025 << 1)))         # ... right before the last record, which is one too
+    w = avr.DeviceWorkload.from_host(0, [r for r, _ in slices], [s for _, s in slices], 0)
+    w.encode_chunked()
+    got, status = w.results()
+    fs = w.final_states.cpu().numpy().reshape(len(slices), ns)
+    for i, (r, s) in enumerate(slices[:good]):
+        want = oracle.cabac_encode(r, s)
+        assert status[i] == 0 and got[i] == want[0] and fs[i].tobytes() == want[1], f"slice {i} n={len(r)}"
+    assert list(status[good:]) == [avr.SLICE_BAD_RECORD] * 5
