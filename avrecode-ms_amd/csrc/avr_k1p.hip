@@ -2,10 +2,10 @@
 // The algorithm and the per-lane functions of phases B-D are in avr_k1p.h; this file maps
 // them to lanes and adds phase A (context-state resolution; see "phase A" below):
 //
-//   k_k1p_census    A   workgroup per 4096 bins      validates every record; which contexts the batch uses
+//   k_k1p_census    A   32 blocks of 4096 bins / WG   which contexts the batch uses, from a 1-in-16 sample of the cache lines
 //   k_k1p_densemap  A   one workgroup                dense numbering of those contexts
 //   k_k1p_tn        A   thread per table entry       state after n = 0..8 bins, per state and bin pattern
-//   k_k1p_local     A   lane per chunk               counting sort of the chunk's bins by context (lane-serial)
+//   k_k1p_local     A   lane per chunk               counting sort of the chunk's bins by context (lane-serial); validates every record
 //   k_k1p_ctxchain  A   lane per (slice, context)    state chain through the slice -> state of every context per chunk
 //   k_k1p_replay    A+B1 lane per chunk              resolved code of every bin, in stream order, and the
 //                                                    chunk's stretch summary for the 4 entry quarters
@@ -58,7 +58,7 @@ constexpr uint32_t kNotUsed = 0xffffu;
 // kChunk bins; what phase A has to find is the state of every context at the start of every chunk
 // (`est`), from which one lane per chunk replays its bins in stream order (k_k1p_replay).
 //
-//   k_k1p_census    workgroup per 4096 bins   validates every record; which contexts the batch uses
+//   k_k1p_census    32 blocks of 4096 bins    which contexts the batch uses (from a sample)
 //   k_k1p_densemap  one workgroup             dense numbering of those contexts
 //   k_k1p_local     lane per chunk            counting sort of the chunk's bins by context, lane-serial: per
 //                                             context the number of bins, and the bins themselves as a bit string
@@ -336,7 +336,10 @@ __global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks
 // The chain is a sequence of dependent look-ups and loads, chunk after chunk: what hides its latency is other
 // waves, and a batch has only slices x contexts lanes to give (44 000 for 512 slices of a 1080p clip).  So a
 // wave takes only kChainLanes of them -- the other lanes stay idle -- which also bounds a step by the longest
-// of kChainLanes runs instead of the longest of 64.
+// of kChainLanes runs instead of the longest of 64.  (Measured and dropped: the batch in two halves on two streams,
+// one kernel apart, so that one half's chains run under the other half's sort and replay.  Those kernels, one lane
+// per chunk at under five waves per SIMD, are short of waves themselves: every kernel of a half got slower by more
+// than the overlap gave back, 2.05 against 1.95 ms per step.)
 constexpr uint32_t kChainLanes = 22, kChainWaves = 8;         // kChainLanes: the fewest lanes a wave takes
 __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint32_t n_slices, uint32_t groups, uint32_t chain_lanes, const int32_t *status,
                                                       const uint8_t *tng, const uint32_t *lbits, const uint16_t *lend,
