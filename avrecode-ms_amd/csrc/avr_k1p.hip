@@ -10,8 +10,7 @@
 //   k_k1p_replay    A+B1 lane per chunk              resolved code of every bin, in stream order, and the
 //                                                    chunk's stretch summary for the 4 entry quarters
 //   k_k1p_b1        B1  lane per chunk               the same summaries from finished codes (resolved-code entry)
-//   k_k1p_b2        B2  workgroup per slice          chain the summaries: entry range + bit position
-//   k_k1p_zero          workgroup per slice          zero the digit sums that will be used
+//   k_k1p_b2        B2  workgroup per slice          chain the summaries: entry range + bit position; zero the digit sums
 //   k_k1p_c         C   lane per chunk               code each stretch, add its digits
 //   k_k1p_d         D   workgroup per slice          finish(), carries (segmented), bytes
 //   k_cabac_encode_codes  lane per slice             serial coder from resolved codes (hand-over of phase D; short slices)
@@ -20,6 +19,8 @@
 // Results are byte-identical to k_cabac_encode (tests/test_gpu_k1p.py); a slice the scheme declines
 // (no coded LPS for 16 chunks) is coded by k_cabac_encode itself.
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, c
 constexpr uint32_t kB2Tile = 1024;
 
 __global__ __launch_bounds__(256) void k_k1p_b2(Plan p, const int32_t *status, const Stretch *st, Entry *en,
-                                                SliceTotals *tot) {
+                                                SliceTotals *tot, uint32_t *S) {
     __shared__ Stretch tile[kB2Tile];
     __shared__ Entry ent[kB2Tile];
     __shared__ uint8_t xq[kB2Tile], qin[kB2Tile];               // exit quarter per entry quarter (2 bits each); entry quarter
@@ -680,13 +681,11 @@ __global__ __launch_bounds__(256) void k_k1p_b2(Plan p, const int32_t *status, c
         __syncthreads();
     }
     if (t == 0) { tot[s].t_total = carry[0]; tot[s].r_final = carry[2]; tot[s].bad = carry[3]; tot[s].pad = 0; }
-}
-
-__global__ __launch_bounds__(256) void k_k1p_zero(Plan p, const SliceTotals *tot, uint32_t *S) {
-    const uint32_t s = blockIdx.x;
-    const uint32_t n = ref_digits(tot[s].t_total) + 2;
+    // the digit sums phase C will add into: zeroed here, where the slice's digit count has just become known
+    __syncthreads();
+    const uint32_t n = ref_digits(carry[0]) + 2;
     uint32_t *d = S + p.dig_off[s];
-    for (uint32_t i = threadIdx.x; i < n; i += 256) d[i] = 0;
+    for (uint32_t i = t; i < n; i += 256) d[i] = 0;
 }
 
 struct DeviceAdder {
@@ -903,6 +902,29 @@ static inline ResolveLayout resolve_layout(size_t n_slices, uint32_t ns, const a
     return L;
 }
 
+// k_k1p_tn's table is a constant: made once per device (on the stream of the first call that needs it, which every
+// later call is ordered behind only by its own use of the device: the event makes that explicit) and kept.
+static hipError_t tn_table(hipStream_t s, const uint8_t **out) {
+    struct Slot { uint8_t *p = nullptr; hipEvent_t ready = nullptr; };
+    static Slot slots[16];
+    static std::mutex mu;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    Slot &x = slots[dev & 15];
+    if (!x.p) {
+        uint8_t *buf = nullptr;
+        if ((e = hipMalloc(reinterpret_cast<void **>(&buf), kTnBytes + 256)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&x.ready, hipEventDisableTiming)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_k1p_tn, dim3((kTnBytes + 255) / 256), dim3(256), 0, s, buf);
+        if ((e = hipEventRecord(x.ready, s)) != hipSuccess) return e;
+        x.p = buf;
+    }
+    *out = x.p;
+    return hipStreamWaitEvent(s, x.ready, 0);
+}
+
 static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const uint8_t *init_states,
                                  const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, int32_t *status, uint8_t *final_states,
                                  uint32_t max_stretch, const Stretch **stretch_out, const DenseHint *hint = nullptr,
@@ -917,7 +939,7 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
     uint32_t *used = reinterpret_cast<uint32_t *>(w + L.meta);   // [32], then n_dense, then the number of slices for the second pass
     uint32_t *n_dense = used + 32, *n_retry = used + 33;
     uint16_t *table = reinterpret_cast<uint16_t *>(w + L.meta + 256), *index = table + 1024;
-    uint8_t *tn = w + L.meta + 256 + 4096;
+    const uint8_t *tn = nullptr;
     p.table = table;
     p.index = index;
     hipError_t e;
@@ -927,7 +949,7 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
         return e;                                                // contexts without bins keep their state
     hipLaunchKernelGGL(k_k1p_census, dim3((pl->total_blocks + kCensusBlocks - 1) / kCensusBlocks), dim3(256), 0, s, p, pl->total_blocks, status, used, stride);
     hipLaunchKernelGGL(k_k1p_densemap, dim3(1), dim3(1024), 0, s, used, table, index, n_dense);
-    hipLaunchKernelGGL(k_k1p_tn, dim3((kTnBytes + 255) / 256), dim3(256), 0, s, tn);
+    if ((e = tn_table(s, &tn)) != hipSuccess) return e;
     uint32_t n_states = 0;
     if (hint && hint->rows) {                                    // sized by the caller's guess, checked by the caller afterwards (DenseHint)
         n_states = hint->rows < ns ? hint->rows : ns;
@@ -999,8 +1021,7 @@ static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, c
     uint32_t *S = reinterpret_cast<uint32_t *>(w);
     const uint32_t chunk_blocks = (pl->total_chunks + 255) / 256;
     if (!have) hipLaunchKernelGGL(k_k1p_b1, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, status, st_own, max_stretch);
-    hipLaunchKernelGGL(k_k1p_b2, dim3(n_slices), dim3(256), 0, s, p, status, st, en, tot);
-    hipLaunchKernelGGL(k_k1p_zero, dim3(n_slices), dim3(256), 0, s, p, tot, S);
+    hipLaunchKernelGGL(k_k1p_b2, dim3(n_slices), dim3(256), 0, s, p, status, st, en, tot, S);
     hipLaunchKernelGGL(k_k1p_c, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
     uint32_t force_retry_every = 0;                              // test switch, see k_k1p_d
     if (const char *f = getenv("AVR_K1P_FORCE_RETRY")) force_retry_every = uint32_t(strtoul(f, nullptr, 10));

@@ -217,12 +217,13 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
 }
 
 // Which contexts the records of a tile / a slice use (one bit per selector < 1024): the census behind the dense
-// renumbering, for the one-lane-per-slice kernel.  One workgroup per 64 slices; plain LDS flag stores, then the
+// renumbering, for the one-lane-per-slice kernel.  One workgroup per kCensusTiles x 64 slices; plain LDS flag stores, then the
 // global words are only touched while a bit is still missing (see k_k1p_census).
 //
 // `stride` > 1: a sample -- every stride-th 16-byte chunk of each slice (a tile's chunk rows r with r % stride ==
 // tile % stride).  The renumbering only has to hold the contexts that matter for the LDS footprint; a slice with a
 // bin in a context the sample missed is handed back by k_cabac_encode and coded by the launch without renumbering.
+constexpr uint32_t kCensusTiles = 8;                              // tiles (of 64 slices) to a workgroup
 template <bool TILED>
 __global__ __launch_bounds__(256) void k_k1_census(const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
                                                    uint32_t n_slices, uint32_t *used, uint32_t stride) {
@@ -239,18 +240,21 @@ __global__ __launch_bounds__(256) void k_k1_census(const void *recs, const uint6
             if (sel < 1024) flag[sel] = 1;
         }
     };
-    if (TILED) {                                                 // the tile is one contiguous run of 16-byte chunks
-        const uint4 *p = reinterpret_cast<const uint4 *>(recs) + off[blockIdx.x];
-        const uint64_t rows = (off[blockIdx.x + 1] - off[blockIdx.x]) >> 6;      // 64 chunks (one per lane) to a row
-        for (uint64_t r = blockIdx.x % stride + uint64_t(stride) * (threadIdx.x >> 6); r < rows; r += 4 * stride) take(p[r * 64 + (threadIdx.x & 63)]);
-    } else {
-        for (uint32_t l = 0; l < 64; l++) {
-            const uint32_t g = blockIdx.x * 64 + l;
-            if (g >= n_slices) break;
-            const uint32_t slice = order ? order[g] : g;
-            const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(recs) + off[slice]);
-            const uint32_t n = (n_bins[slice] + 7) >> 3;
-            for (uint32_t i = (blockIdx.x + l) % stride + stride * threadIdx.x; i < n; i += 256 * stride) take(p[i]);
+    const uint32_t n_tiles = (n_slices + 63) / 64;
+    for (uint32_t tile = blockIdx.x * kCensusTiles; tile < n_tiles && tile < (blockIdx.x + 1) * kCensusTiles; tile++) {
+        if (TILED) {                                             // the tile is one contiguous run of 16-byte chunks
+            const uint4 *p = reinterpret_cast<const uint4 *>(recs) + off[tile];
+            const uint64_t rows = (off[tile + 1] - off[tile]) >> 6;              // 64 chunks (one per lane) to a row
+            for (uint64_t r = tile % stride + uint64_t(stride) * (threadIdx.x >> 6); r < rows; r += 4 * stride) take(p[r * 64 + (threadIdx.x & 63)]);
+        } else {
+            for (uint32_t l = 0; l < 64; l++) {
+                const uint32_t g = tile * 64 + l;
+                if (g >= n_slices) break;
+                const uint32_t slice = order ? order[g] : g;
+                const uint4 *p = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(recs) + off[slice]);
+                const uint32_t n = (n_bins[slice] + 7) >> 3;
+                for (uint32_t i = (tile + l) % stride + stride * threadIdx.x; i < n; i += 256 * stride) take(p[i]);
+            }
         }
     }
     __syncthreads();
@@ -581,7 +585,7 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
         uint32_t *used = reinterpret_cast<uint32_t *>(scratch);
         uint16_t *t = reinterpret_cast<uint16_t *>(scratch + 256);
         if ((err = hipMemsetAsync(used, 0, 256, s)) != hipSuccess) return err;
-        const dim3 cgrid((n_slices + 63) / 64);
+        const dim3 cgrid(((n_slices + 63) / 64 + kCensusTiles - 1) / kCensusTiles);
         const char *cs = getenv("AVR_CENSUS_STRIDE");
         const uint32_t stride = cs && atoi(cs) > 0 ? uint32_t(atoi(cs)) : kCensusStride;
         retry = stride > 1;

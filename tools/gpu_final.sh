@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { tail -5 $O/smoke.log; exit 1; }
 tail -1 $O/smoke.log
 python3 $R/bench.py > $O/bench_w2.json 2> $O/bench_w2.err || exit 1
-python3 $R/bench.py --workload 3 --no-cpu-baseline > $O/bench_w3.json 2>> $O/bench.err || exit 1
+python3 $R/bench.py --workload 3 > $O/bench_w3.json 2>> $O/bench.err || exit 1
 python3 $R/bench.py --workload 4 > $O/bench_w4.json 2>> $O/bench.err || exit 1
 python3 $R/bench.py --workload 5 > $O/bench_w5.json 2>> $O/bench.err || exit 1
 python3 $R/bench.py --workload 5 --kind range > $O/bench_w5_k2.json 2>> $O/bench.err || exit 1
