@@ -428,12 +428,43 @@ __device__ __forceinline__ CodeEntry device_code_entry(uint32_t c);
 // state's four range quarters, next state | resolved code << 8 | B1's meta << 16 }.
 constexpr uint32_t kStBypass = 128, kStTerminate = 129, kStPad = 130, kStNone = 131, kReplayStates = 132;
 
+// B1's four candidate ranges, two to a register (16 bits each), stepped with the packed 16-bit instructions: per pair
+// one byte permute picks each candidate's LPS range out of the state's row by the candidate's own range quarter, and the
+// LPS side (range renormalised, its shift) comes out of two more rows of the same shape instead of a count-leading-zeros
+// per candidate (codes2[code] = { rown: low byte of rLPS << shift per quarter, shrow: the shift per quarter }).
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)); }
+__device__ __forceinline__ uint32_t pk_shl(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) << __builtin_bit_cast(u16x2, b)); }
+__device__ __forceinline__ uint32_t pk_shr8(uint32_t a) { return (a >> 8) & 0x00ff00ffu; }
+// one bin on a pair of candidates (step_range of avr_k1p.h, twice): returns the two shifts, packed
+__device__ __forceinline__ uint32_t step_pair(uint32_t &Rp, uint32_t row, uint32_t rown, uint32_t shrow, bool sym, uint32_t extra) {
+    const uint32_t sel = ((Rp >> 6) & 0x00030003u) | 0x0c000c00u;   // bytes 0 and 2: the candidate's quarter; 1 and 3: zero
+    const uint32_t rl = __builtin_amdgcn_perm(row, row, sel);
+    const uint32_t rm = pk_sub(Rp, rl);                              // MPS side: range - rLPS, in [128, 511]
+    const uint32_t shm = pk_shr8(rm) ^ 0x00010001u;                  // one shift iff below 256
+    const uint32_t rn = __builtin_amdgcn_perm(rown, rown, sel) | 0x01000100u;   // LPS side, renormalised: in [256, 511]
+    const uint32_t shl = __builtin_amdgcn_perm(shrow, shrow, sel);
+    Rp = sym ? rn : pk_shl(rm, shm);
+    return (sym ? shl : shm) + extra;
+}
+
 __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *est, uint8_t *res,
                                                     const int32_t *status, Stretch *stretch, uint32_t max_stretch) {
     extern __shared__ uint32_t replay_lds[];                     // per wave: state dwords [(nk+8)/4][64]
     __shared__ uint2 info[2 * kReplayStates];
+    __shared__ uint2 codes2[256];
     __shared__ uint32_t sel_off[2048];
     const uint32_t lane = threadIdx.x & 63, nk = p.n_states;
+    for (uint32_t c = threadIdx.x; c < 256; c += blockDim.x) {
+        const uint32_t row = device_code_entry(c).row;
+        uint32_t rown = 0, shrow = 0;
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t rl = (row >> (8 * q)) & 0xffu;
+            if (rl) { uint32_t sh; const uint32_t rn = post_lps_range(row, q, &sh); rown |= (rn & 0xffu) << (8 * q); shrow |= sh << (8 * q); }
+        }
+        codes2[c] = make_uint2(rown, shrow);
+    }
     uint8_t *stb = reinterpret_cast<uint8_t *>(replay_lds) + (threadIdx.x >> 6) * (((nk + 8) >> 2) << 8) + lane * 4;
     for (uint32_t sel = threadIdx.x; sel < 2048; sel += blockDim.x) {
         // contexts get their dense id; 1024 (bypass), 1025 (terminate), 1026 (no-op) -> nk+1, nk+2, nk+3; the rest nk / nk+4
@@ -480,25 +511,35 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
     // ---- B1 (the logic of b1_stretch): 0 = looking for the LPS that opens the stretch, 1 = four candidate ranges,
     // 2 = they have merged, 3 = closed
     const uint32_t limit = i0 + kChunk;
-    uint32_t mode = 0, R[4] = {510, 510, 510, 510}, T[4] = {0, 0, 0, 0}, Rm = 510, Tm = 0, end = 0;
+    // candidates 0, 1 in Rp0 (low, high half), 2, 3 in Rp1; Tp0 / Tp1: their shifts since the last flush into T[]
+    uint32_t mode = 0, Rp0 = 0x01fe01feu, Rp1 = 0x01fe01feu, Tp0 = 0, Tp1 = 0, T[4] = {0, 0, 0, 0}, Rm = 510, Tm = 0, end = 0;
     bool merged = false;
     if (c == 0) { o.first = 0; mode = 2; merged = true; }        // opens at bin 0 with the initial range 510 (cabac_code.h:30)
+    auto flush_t = [&]() {                                       // at least every 8 bins: 8 x 9 shifts fit 16 bits with room
+        T[0] += Tp0 & 0xffffu; T[1] += Tp0 >> 16; T[2] += Tp1 & 0xffffu; T[3] += Tp1 >> 16;
+        Tp0 = Tp1 = 0;
+    };
     auto one = [&](uint32_t idx, const uint2 &e) {               // bin idx (< n) with table entry e, any mode
         const CodeEntry ce{e.x, e.y >> 16};
         const bool boundary = ce.meta & 1u;                      // a coded LPS (code_is_boundary)
         if (mode == 0) {
             if (idx < i1 && boundary) {
                 o.first = idx;
-                for (uint32_t q = 0; q < 4; q++) { uint32_t sh; R[q] = post_lps_range(ce.row, q, &sh); }
+                const uint32_t rown = codes2[(e.y >> 8) & 0xffu].x;              // post_lps_range for the four quarters
+                Rp0 = __builtin_amdgcn_perm(rown, rown, 0x0c010c00u) | 0x01000100u;
+                Rp1 = __builtin_amdgcn_perm(rown, rown, 0x0c030c02u) | 0x01000100u;
                 mode = 1;
             }
         } else if (mode == 1) {
             const bool closing = idx >= limit && boundary;
             if (closing)
-                for (uint32_t q = 0; q < 4; q++) o.exit_q |= uint8_t(((R[q] >> 6) & 3) << (2 * q));
-            for (uint32_t q = 0; q < 4; q++) T[q] += step_range(ce, &R[q]);
+                o.exit_q |= uint8_t(((Rp0 >> 6) & 3u) | ((Rp0 >> 22) & 3u) << 2 | ((Rp1 >> 6) & 3u) << 4 | ((Rp1 >> 22) & 3u) << 6);
+            const uint2 e2 = codes2[(e.y >> 8) & 0xffu];
+            const uint32_t extra = (ce.meta >> 8) * 0x00010001u;                 // a bypass bin's one shift
+            Tp0 = pk_add(Tp0, step_pair(Rp0, ce.row, e2.x, e2.y, boundary, extra));
+            Tp1 = pk_add(Tp1, step_pair(Rp1, ce.row, e2.x, e2.y, boundary, extra));
             if (closing) { end = idx + 1; mode = 3; }
-            else if (R[0] == R[1] && R[1] == R[2] && R[2] == R[3]) { Rm = R[0]; mode = 2; merged = true; }
+            else if (Rp0 == Rp1 && (Rp0 >> 16) == (Rp0 & 0xffffu)) { Rm = Rp0 & 0xffffu; mode = 2; merged = true; }
         } else if (mode == 2) {
             const bool closing = idx >= limit && boundary;
             if (closing) o.exit_q = uint8_t(((Rm >> 6) & 3) * 0x55u);
@@ -529,8 +570,21 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
         if (mode == 2 && base + 8 <= i1) {                       // merged and inside the chunk: nothing can close the stretch
 #pragma unroll
             for (uint32_t j = 0; j < 8; j++) { const CodeEntry ce{e[j].x, e[j].y >> 16}; Tm += step_range(ce, &Rm); }
+        } else if (mode == 1 && base + 8 <= i1) {                // four candidates, inside the chunk: the same, and no branch per bin
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint2 e2 = codes2[(e[j].y >> 8) & 0xffu];
+                const bool sym = (e[j].y >> 16) & 1u;
+                const uint32_t extra = (e[j].y >> 24) * 0x00010001u;
+                Tp0 = pk_add(Tp0, step_pair(Rp0, e[j].x, e2.x, e2.y, sym, extra));
+                Tp1 = pk_add(Tp1, step_pair(Rp1, e[j].x, e2.x, e2.y, sym, extra));
+            }
+            flush_t();
+            // candidates that have met stay together: looking once per group is enough, and the group's shifts are in T[] either way
+            if (Rp0 == Rp1 && (Rp0 >> 16) == (Rp0 & 0xffffu)) { Rm = Rp0 & 0xffffu; mode = 2; merged = true; }
         } else if (mode != 3) {
             for (uint32_t j = 0; j < 8; j++) if (base + j < n) one(base + j, e[j]);
+            flush_t();
         }
     };
     // a slice's records are padded with no-ops to a multiple of 8, its codes to a multiple of 16
@@ -574,13 +628,15 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
             uint2 e[8];
             eight(*reinterpret_cast<const U4 *>(r + i), c0, c1, e);
             for (uint32_t j = 0; j < 8; j++) if (i + j < n && mode != 3) one(i + j, e[j]);
+            flush_t();
         }
     }
     if (o.first != kNone) {
         o.end = mode != 3 ? n : end;                             // not closed: ran to the end of the slice
         for (uint32_t q = 0; q < 4; q++) {                       // once merged, Rm / Tm carried on for all four candidates
+            const uint32_t rq = ((q & 2u) ? Rp1 : Rp0) >> (16 * (q & 1u)) & 0xffffu;
             o.t_exit[q] = T[q] + (merged ? Tm : 0u);
-            o.r_exit[q] = uint16_t(merged ? Rm : R[q]);
+            o.r_exit[q] = uint16_t(merged ? Rm : rq);
         }
     }
     stretch[gc] = o;
