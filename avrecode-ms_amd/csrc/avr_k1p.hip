@@ -340,7 +340,9 @@ __global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks
 // of kChainLanes runs instead of the longest of 64.  (Measured and dropped: the batch in two halves on two streams,
 // one kernel apart, so that one half's chains run under the other half's sort and replay.  Those kernels, one lane
 // per chunk at under five waves per SIMD, are short of waves themselves: every kernel of a half got slower by more
-// than the overlap gave back, 2.05 against 1.95 ms per step.)
+// than the overlap gave back, 2.05 against 1.95 ms per step.  Also without effect: twice the read-ahead (end positions
+// eight chunks ahead, windows four), and whole-byte look-ups without the arithmetic on n between them -- a step is the
+// hottest lane's seven or so dependent LDS round trips, and neither its loads nor its VALU work.)
 constexpr uint32_t kChainLanes = 22, kChainWaves = 8;         // kChainLanes: the fewest lanes a wave takes
 __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint32_t n_slices, uint32_t groups, uint32_t chain_lanes, const int32_t *status,
                                                       const uint8_t *tng, const uint32_t *lbits, const uint16_t *lend,
