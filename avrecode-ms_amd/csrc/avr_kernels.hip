@@ -19,6 +19,9 @@
 //                       every context, so the data-dependent state read and write of a bin
 //                       never conflict across lanes.
 #include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -94,13 +97,70 @@ struct CabacLane {
     }
 };
 
+// The same bin in NORMALISED form (the form of K1p's phase C, avr_k1p.h: c_stretch): the range as 9 bits R in [256, 511]
+// with the reference's range = R << e (cabac_code.h:37-41), low as the 64-bit integer L2 = 2 low >> e, and sp = 15 - e the
+// bit of L2 / 2 where the next 16-bit digit of the code string begins.  A digit is due when e drops to 0 (sp >= 15,
+// arithmetic_code.h:115-122) -- but nothing forces it out at that very bin: L2 has room for four more bins (28 shifts at
+// most), so the caller takes the due digits after every fourth bin, at the same instruction for all lanes of the wave,
+// where the reference's form has one lane or another in its emit branch at almost every bin.  A digit taken late has
+// the carries of the bins in between in it (bit 16 set): carry_back(), as for low >= fixed_one in the reference's form.
+struct CabacLaneN {
+    uint32_t R;
+    uint64_t L2;
+    int32_t sp;
+    CabacEncoder e;                                              // its writer, and finish() in the reference's form
+
+    __device__ __forceinline__ void init(uint8_t *out, uint32_t capacity) {
+        R = 510; L2 = 0; sp = -7;                                // range 510 << 22 = 0x7F800000 (cabac_code.h:30)
+        e.init(0x7F800000u, out, capacity);
+    }
+    __device__ __forceinline__ void bin(uint32_t rec, uint32_t off, const uint2 *tab, uint8_t *st_lane) {
+        uint8_t *spb = st_lane + off;
+        uint32_t s = *spb;
+        asm volatile("" : "+v"(s));                              // see CabacLane::bin
+        uint2 ent = tab[s];
+        asm volatile("" : "+v"(ent.x), "+v"(ent.y));
+        const uint32_t byp = ent.y >> 31;                                        // cabac_code.h:52-54
+        const uint32_t sym = (rec ^ s) & 1u & ~(ent.y >> 30);                    // the bin is not valMPS (:34); the bin itself for bypass
+        const bool lps = sym & ~byp;
+        const uint32_t rl = (ent.x >> ((R >> 3) & 24u)) & 0xffu;                 // rangeTabLPS[p][quarter] (:39-41); 0 for bypass / no-op
+        const uint32_t rm = R - rl;
+        const uint32_t shm = ((rm >> 8) & 1u) ^ 1u;                              // rm in [128, 511]: one shift iff below 256
+        const uint32_t shl = uint32_t(__builtin_clz(rl | 1u)) - 23u;             // LPS side: range = rLPS, renormalised
+        const uint32_t v = byp ? R : 2u * rm;                                    // what a 1 adds to low, in half units
+        const uint32_t sh0 = lps ? shl : shm, sh = sh0 + byp;
+        L2 = (L2 + (sym ? v : 0u)) << sh;
+        R = (lps ? rl : rm) << sh0;
+        sp += int32_t(sh);
+        *spb = uint8_t(ent.y >> (8 * sym));                                      // cabac_code.h:43-47
+    }
+    __device__ __forceinline__ void digits() {                   // every digit that is due, oldest first
+        while (sp >= 15) {
+            uint32_t d = uint32_t(L2 >> (sp + 1));
+            L2 &= (uint64_t(2) << sp) - 1;
+            if (__builtin_expect(d >> 16, 0)) { e.carry_back(); d &= 0xffffu; }
+            e.w.put16_even(d);
+            sp -= 16;
+        }
+    }
+    __device__ void finish() {                                   // back to the reference's (low, range), then its finish()
+        digits();
+        const uint32_t ex = uint32_t(15 - sp);                   // 1 .. 22
+        uint64_t low = L2 << (ex - 1);
+        if (low >= CabacEncoder::kOne) { e.carry_back(); low -= CabacEncoder::kOne; }
+        e.low = uint32_t(low);
+        e.range = R << ex;
+        e.finish();
+    }
+};
+
 constexpr uint32_t kCensusStride = 16;                           // the one-lane-per-slice kernel renumbers from a 1-in-16 sample
 constexpr uint32_t kK1Waves = 4;                                 // waves per workgroup (fewer when the state rows are large): they share the two tables
 
 // table / index: the dense renumbering of the batch's contexts (k_k1p_densemap), or null: contexts as the caller
 // numbers them.  n_rows: contexts the kernel keeps states for (dense count, or n_states); init_states / final_states
 // rows are n_states wide, in the caller's numbering.
-template <bool TILED>
+template <bool TILED, bool NORM>
 __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
     uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const uint16_t *table, const uint16_t *index, uint32_t n_rows,
@@ -163,10 +223,11 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     }
     __syncthreads();
 
-    CabacLane L;
+    typename std::conditional<NORM, CabacLaneN, CabacLane>::type L;
     const uint64_t o0 = in_range ? out_off[slice] : 0;
     const uint32_t cap = in_range ? uint32_t(out_off[slice + 1] - o0) : 0;
-    L.e.init(0x7F800000u, out + o0, cap);                        // cabac_code.h:30
+    if constexpr (NORM) L.init(out + o0, cap);
+    else L.e.init(0x7F800000u, out + o0, cap);                   // cabac_code.h:30
 
     const ChunkSource<TILED> src(recs, off, in_range ? g : 0, slice);
     const uint32_t n_chunks = (nb + 7) >> 3;
@@ -188,6 +249,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t rec = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
             L.bin(rec, offs[k], tab, st_lane);
+            if constexpr (NORM) { if ((k & 3) == 3) L.digits(); }
             const uint32_t t0 = rec == kTerm1 ? c * 8 + k : 0xffffffffu;
             term_at = term_at < t0 ? term_at : t0;
         }
@@ -198,6 +260,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
         if (active) {
             const bool missed = st_lane[(((n_rows + 3) >> 2) << 8) + ((n_rows + 3) & 3)] == 135u;
             if (term_at != 0xffffffffu && term_at + 1 < nb) st = AVR_SLICE_BAD_RECORD;   // a bin after finish()
+            else if constexpr (NORM) L.finish();
             else L.e.finish();                                   // cabac_code.h:63-65 / ~encoder(), arithmetic_code.h:100
             L.e.w.flush();
             if (st == AVR_SLICE_OK && L.e.w.n > cap) st = AVR_SLICE_OVERFLOW;
@@ -615,7 +678,13 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
         const uint32_t waves = per_wave * kK1Waves <= 60 * 1024 ? kK1Waves : per_wave * 2 <= 60 * 1024 ? 2 : 1;
         const uint32_t lds = waves * per_wave;
         const dim3 grid((n_slices + 64 * waves - 1) / (64 * waves)), block(64 * waves);
-        auto kern = tiled ? k_cabac_encode<true> : k_cabac_encode<false>;
+        // AVR_K1_FORM=norm: the coder in normalised form with the digits taken every fourth bin, in step across the wave
+        // (CabacLaneN).  Same bytes; measured on config 5 at the same 2.63 ms per step as the reference's form (what its
+        // emit branch costs, the 64-bit low of the other form costs again), so the form that reads like cabac_code.h stays.
+        const char *form = getenv("AVR_K1_FORM");
+        const bool norm = form && strcmp(form, "norm") == 0;
+        auto kern = tiled ? (norm ? k_cabac_encode<true, true> : k_cabac_encode<true, false>)
+                          : (norm ? k_cabac_encode<false, true> : k_cabac_encode<false, false>);
         if (lds > 48 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
             if (e != hipSuccess) return e;

@@ -69,8 +69,12 @@ def test_range_golden_vectors(avr):
 
 # ------------------------------------------------------------------ random, ragged, edge cases
 
+@pytest.mark.parametrize("form", ["ref", "norm"])
 @pytest.mark.parametrize("n_states", [4, 64, 460, 1024])
-def test_cabac_random_ragged(avr, oracle, n_states):
+def test_cabac_random_ragged(avr, oracle, n_states, form, monkeypatch):
+    """form: the one-lane-per-slice coder as the reference writes it (shipped), and in normalised form with the digits
+    taken every fourth bin in step across the wave (AVR_K1_FORM=norm, kept as a measured variant)."""
+    monkeypatch.setenv("AVR_K1_FORM", form)
     rng = np.random.default_rng(100 + n_states)
     slices = []
     for i in range(200):                          # 3+ tiles, lengths from 0 to a few thousand

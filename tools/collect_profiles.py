@@ -29,15 +29,20 @@ def short(name):
     return name.split("(")[0].replace("void ", "").replace("avr::", "")
 
 
+PMC_STEPS = 4        # tools/gpu_final.sh runs the counter passes with --steps 3 --warmup 1: four identical steps
+
+
 def per_kernel(path, counter, steps_key="avr::"):
-    """mean counter value per launch, per kernel of this library, skipping the warm-up step's launches"""
+    """counter value per STEP, per kernel of this library: the sum over all launches of the run / the run's steps
+    (a kernel launched twice per step -- the coder and its hand-back launch -- counts twice, one made once per process
+    -- the state-walk table -- a quarter)"""
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and "avr::" in r["Kernel_Name"]
             and "synth" not in r["Kernel_Name"] and "context_" not in r["Kernel_Name"] and "states_permute" not in r["Kernel_Name"]
             and "pack_tiles" not in r["Kernel_Name"]]
     by = collections.defaultdict(list)
     for r in rows:
         by[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    return {k: sum(v[1:]) / max(len(v) - 1, 1) if len(v) > 1 else v[0] for k, v in by.items()}   # first launch = warm-up
+    return {k: sum(v) / PMC_STEPS for k, v in by.items()}
 
 
 traffic = {}
@@ -58,7 +63,7 @@ for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches o
         "fetch_bytes_corrected_x2": fsum * 1024 * 2, "write_bytes": wsum * 1024,
         "hbm_bytes_per_launch": fsum * 1024 * 2 + wsum * 1024,
         "per_kernel_FETCH_SIZE_KB": fetch, "per_kernel_WRITE_SIZE_KB": write,
-        "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE), averaged over the launches of the timed steps; FETCH_SIZE "
+        "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE), all launches of the run / its 4 steps; FETCH_SIZE "
                 "doubled per the gfx950 wide-read rule (uncalibrated for byte gathers)"}
     # issue / wait counters of the same workload, one line per kernel
     sq = one(f"w{w}_sq/**/*counter_collection.csv")
