@@ -231,9 +231,9 @@ def digest(chunks):
     return h.hexdigest()
 
 
-@pytest.mark.parametrize("workload,n_slices", [(2, 512), (5, 65536)])
+@pytest.mark.parametrize("workload,n_slices", [(2, 512), (5, 65536), (5, 1048576)])
 def test_full_size_properties(avr, oracle, workload, n_slices):
-    """Config 2 at its own size and a 64Ki-slice cut of config 5: statuses, idempotence, sampled byte
+    """Config 2 and config 5 at their own size (and a 64Ki-slice cut of config 5): statuses, idempotence, sampled byte
     equality with the oracle, decode round trip of the samples, and a checksum of checksums over
     every slice against the threaded oracle."""
     w = avr.DeviceWorkload.synth(workload, n_slices, 0, 0, 1000)
