@@ -122,12 +122,20 @@ struct Stretch {
     uint8_t pad[2];
 };
 
-// Visit the resolved codes res[from .. n) in order, 16 bytes per load.  f(i, code) returns true
-// to stop.  res must be 16-byte aligned and readable up to the next multiple of 16.
-template <class F>
-AVR_HD void for_codes(const uint8_t *res, uint32_t from, uint32_t n, F &&f) {
+// Where a slice's resolved codes are read from: load16(i), i a multiple of 16, gives codes i .. i+15; byte(i) one code.
+// LinearCodes: the slice's codes in a row (the layout of the public entry points: 16-byte aligned, readable up to the
+// next multiple of 16).  The kernels have a second one for their own, wave-interleaved buffer (avr_k1p.hip).
+struct LinearCodes {
+    const uint8_t *p;
+    AVR_HD U4 load16(uint32_t i) const { return *reinterpret_cast<const U4 *>(p + i); }
+    AVR_HD uint32_t byte(uint32_t i) const { return p[i]; }
+};
+
+// Visit the resolved codes [from .. n) of `src` in order, 16 bytes per load.  f(i, code) returns true to stop.
+template <class Src, class F>
+AVR_HD void for_codes_in(const Src &src, uint32_t from, uint32_t n, F &&f) {
     for (uint32_t base = from & ~15u; base < n; base += 16) {
-        const U4 v = *reinterpret_cast<const U4 *>(res + base);
+        const U4 v = src.load16(base);
         uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
@@ -144,6 +152,8 @@ AVR_HD void for_codes(const uint8_t *res, uint32_t from, uint32_t n, F &&f) {
         }
     }
 }
+template <class F>
+AVR_HD void for_codes(const uint8_t *res, uint32_t from, uint32_t n, F &&f) { for_codes_in(LinearCodes{res}, from, n, f); }
 
 // The same for codes that all get the same treatment: g(code) for every code of res[from .. to), no
 // index, no early exit.  The bulk is taken 64 bytes per lane per trip (four 16-byte loads issued
@@ -338,12 +348,12 @@ AVR_HD uint32_t ref_digits(uint32_t t) { return t <= 21 ? 0 : (t - 21 + 15) / 16
 // bin, at the same place for every lane of a wave -- where the reference's form has one lane or
 // another emitting at almost every bin.  A digit taken late has the carries of the bins in between
 // already in it (it can reach 2^17); the sums are integers and phase D carries them on.
-template <class Adder>
-AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, uint32_t chunk,
-                      const CodeEntry *codes, Adder &S) {
+template <class Src, class Adder>
+AVR_HD void c_stretch_in(const Src &src, const Stretch &st, const Entry &en, uint32_t chunk,
+                         const CodeEntry *codes, Adder &S) {
     uint32_t R, from;
     if (chunk == 0) { R = 510; from = 0; }
-    else { uint32_t sh; R = post_lps_range(codes[res[st.first]].row, en.q, &sh); from = st.first + 1; }
+    else { uint32_t sh; R = post_lps_range(codes[src.byte(st.first)].row, en.q, &sh); from = st.first + 1; }
     const uint32_t phase = en.t_start & 15, g0 = en.t_start >> 4;
     uint64_t L2 = 0;
     int sp = int(phase) - 7;                               // e = 22 - phase at the start (cabac_code.h:30 shifted onto the digit grid)
@@ -381,21 +391,21 @@ AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, ui
         auto group16 = [&](const U4 &v) { four(v.x); four(v.y); four(v.z); four(v.w); };
         // code by code up to a 16-byte boundary, 16-byte groups up to a cache line, then lines, and back down
         const uint32_t head_end = ((from + 15) & ~15u) < to ? ((from + 15) & ~15u) : to;
-        for_codes(res, from, head_end, [&](uint32_t, uint32_t c) { bin(c); digits(); return false; });
+        for_codes_in(src, from, head_end, [&](uint32_t, uint32_t c) { bin(c); digits(); return false; });
         uint32_t base = head_end;
-        for (; (base & 63) && base + 16 <= to; base += 16) group16(*reinterpret_cast<const U4 *>(res + base));
+        for (; (base & 63) && base + 16 <= to; base += 16) group16(src.load16(base));
         U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
-        if (base + 64 <= to) { const U4 *p = reinterpret_cast<const U4 *>(res + base); v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3]; }
+        if (base + 64 <= to) { v0 = src.load16(base); v1 = src.load16(base + 16); v2 = src.load16(base + 32); v3 = src.load16(base + 48); }
         for (; base + 64 <= to; base += 64) {              // a whole cache line per lane per trip, the next one in flight
             const uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-            if (base + 128 <= to) { const U4 *q = reinterpret_cast<const U4 *>(res + base + 64); v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
+            if (base + 128 <= to) { v0 = src.load16(base + 64); v1 = src.load16(base + 80); v2 = src.load16(base + 96); v3 = src.load16(base + 112); }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 4
 #endif
             for (uint32_t k = 0; k < 16; k++) four(w[k]);
         }
-        for (; base + 16 <= to; base += 16) group16(*reinterpret_cast<const U4 *>(res + base));
-        if (base < to) for_codes(res, base, to, [&](uint32_t, uint32_t c) { bin(c); digits(); return false; });
+        for (; base + 16 <= to; base += 16) group16(src.load16(base));
+        if (base < to) for_codes_in(src, base, to, [&](uint32_t, uint32_t c) { bin(c); digits(); return false; });
     }
     // what is left is the coder's window: the top of digit g0 + j (with any carry) and 15 - e bits of the next
     if (sp >= 0) {
@@ -404,6 +414,12 @@ AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, ui
     } else {
         S.add(g0 + j, uint32_t(L2 << (-sp - 1)) );
     }
+}
+
+template <class Adder>
+AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, uint32_t chunk,
+                      const CodeEntry *codes, Adder &S) {
+    c_stretch_in(LinearCodes{res}, st, en, chunk, codes, S);
 }
 
 // ------------------------------------------------------------------ phase D (one lane per slice)

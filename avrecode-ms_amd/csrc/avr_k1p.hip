@@ -52,6 +52,23 @@ struct Plan {                       // device pointers of the caller's plan (avr
 };
 constexpr uint32_t kNotUsed = 0xffffu;
 
+// The kernels' own buffer of resolved codes, wave-interleaved: 16-byte group g (of 64) of global chunk gc is at
+//   base + (((gc / 64) * 64 + g) * 64 + gc % 64) * 16,
+// so the 64 lanes of a wave -- 64 consecutive chunks -- store (k_k1p_replay) and load (k_k1p_c) group g as one
+// contiguous kilobyte, where slice-major codes cost a cache line per lane per 16-byte access.  chunk0 = the slice's
+// first global chunk; i = index of a code in the slice.  (The public two-stage entry points keep slice-major codes.)
+struct TileCodes {
+    const uint8_t *base;
+    uint32_t chunk0;
+    __device__ __forceinline__ size_t at(uint32_t i) const {
+        const uint32_t gc = chunk0 + (i >> 10), g = (i >> 4) & 63u;
+        return ((size_t(gc >> 6) * 64 + g) * 64 + (gc & 63u)) * 16;
+    }
+    __device__ __forceinline__ U4 load16(uint32_t i) const { return *reinterpret_cast<const U4 *>(base + at(i)); }
+    __device__ __forceinline__ uint32_t byte(uint32_t i) const { return base[at(i) + (i & 15u)]; }
+};
+__host__ __device__ inline uint64_t tile_codes_bytes(uint32_t total_chunks) { return (uint64_t(total_chunks) + 63) / 64 * 64 * 1024; }
+
 // ------------------------------------------------------------------ phase A
 //
 // Context states evolve per context, independent of low / range (cabac_code.h:43-47): the state a bin is
@@ -451,6 +468,7 @@ __device__ __forceinline__ uint32_t step_pair(uint32_t &Rp, uint32_t row, uint32
     return (sym ? shl : shm) + extra;
 }
 
+template <bool TILE_CODES>
 __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *est, uint8_t *res,
                                                     const int32_t *status, Stretch *stretch, uint32_t max_stretch) {
     extern __shared__ uint32_t replay_lds[];                     // per wave: state dwords [(nk+8)/4][64]
@@ -509,7 +527,12 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
         for (uint32_t j = 0; j < 5; j++) stb[((nk + j) >> 2) * 256 + ((nk + j) & 3)] = uint8_t(pseudo[j]);
     }
     const uint16_t *r = p.recs + p.rec_off[s];
-    uint8_t *ro = res + p.res_off[s];
+    // where the chunk's codes go: bin i of the slice at ro + (i - ro_i0) * ro_scale / 16 ... in whole 16-byte groups only
+    uint8_t *ro = TILE_CODES ? res + ((size_t(gc >> 6) * 64) * 64 + (gc & 63u)) * 16 : res + p.res_off[s];
+    auto put16 = [&](uint32_t i, const U4 &v) {                  // codes i .. i+15 of the slice (i a multiple of 16, in this chunk)
+        if (TILE_CODES) *reinterpret_cast<U4 *>(ro + size_t((i - i0) >> 4) * 1024) = v;
+        else *reinterpret_cast<U4 *>(ro + i) = v;
+    };
     // ---- B1 (the logic of b1_stretch): 0 = looking for the LPS that opens the stretch, 1 = four candidate ranges,
     // 2 = they have merged, 3 = closed
     const uint32_t limit = i0 + kChunk;
@@ -609,8 +632,8 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
             eight(v1, a.z, a.w, e); b1_group(i + 8, e);
             eight(v2, b.x, b.y, e); b1_group(i + 16, e);
             eight(v3, b.z, b.w, e); b1_group(i + 24, e);
-            *reinterpret_cast<U4 *>(ro + i) = a;
-            *reinterpret_cast<U4 *>(ro + i + 16) = b;
+            put16(i, a);
+            put16(i + 16, b);
             v0 = n0; v1 = n1; v2 = n2; v3 = n3;
         }
         for (; i < i1; i += 16) {
@@ -621,7 +644,7 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
             uint2 e[8];
             eight(t0, a.x, a.y, e); b1_group(i, e);
             eight(t1, a.z, a.w, e); b1_group(i + 8, e);
-            *reinterpret_cast<U4 *>(ro + i) = a;
+            put16(i, a);
         }
         if (mode == 0) mode = 3;                                 // no LPS in the chunk: no stretch opens here (first stays kNone)
         // past the chunk: on through the next chunk's bins until the stretch closes (codes not written: not this lane's)
@@ -752,6 +775,7 @@ struct DeviceAdder {
     __device__ void add(uint32_t i, uint32_t v) { atomicAdd(&S[i], v); }
 };
 
+template <bool TILE_CODES>
 __global__ __launch_bounds__(256) void k_k1p_c(Plan p, uint32_t total_chunks, const uint8_t *res,
                                                const Stretch *st, const Entry *en, const SliceTotals *tot,
                                                uint32_t *S) {
@@ -765,7 +789,8 @@ __global__ __launch_bounds__(256) void k_k1p_c(Plan p, uint32_t total_chunks, co
     const uint32_t slice = p.chunk_slice[gc];
     if (tot[slice].bad) return;
     DeviceAdder add{S + p.dig_off[slice]};
-    c_stretch(res + p.res_off[slice], o, en[gc], gc - p.chunk_base[slice], codes, add);
+    if (TILE_CODES) c_stretch_in(TileCodes{res, p.chunk_base[slice]}, o, en[gc], gc - p.chunk_base[slice], codes, add);
+    else c_stretch(res + p.res_off[slice], o, en[gc], gc - p.chunk_base[slice], codes, add);
 }
 
 // ------------------------------------------------------------------ phase D
@@ -986,7 +1011,8 @@ static hipError_t tn_table(hipStream_t s, const uint8_t **out) {
 static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const uint8_t *init_states,
                                  const avr_chunk_plan *pl, uint8_t *w, uint8_t *res, int32_t *status, uint8_t *final_states,
                                  uint32_t max_stretch, const Stretch **stretch_out, const DenseHint *hint = nullptr,
-                                 uint32_t stride = 1, bool second_pass = false, uint32_t *retry_count = nullptr) {
+                                 uint32_t stride = 1, bool second_pass = false, uint32_t *retry_count = nullptr,
+                                 bool tile_codes = false) {
     const uint32_t ns = p.ns_full;
     const ResolveLayout L = resolve_layout(n_slices, ns, pl);
     uint32_t *lbits = reinterpret_cast<uint32_t *>(w + L.lbits);
@@ -1058,11 +1084,12 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
     const uint32_t per_wave = ((n_states + 8) / 4) * 256;
     const uint32_t replay_waves = per_wave * 4 <= 48 * 1024 ? 4 : per_wave * 2 <= 48 * 1024 ? 2 : 1;
     const uint32_t replay_lds = replay_waves * per_wave;
+    auto replay = tile_codes ? k_k1p_replay<true> : k_k1p_replay<false>;
     if (replay_lds > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_k1p_replay), hipFuncAttributeMaxDynamicSharedMemorySize, int(replay_lds));
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(replay), hipFuncAttributeMaxDynamicSharedMemorySize, int(replay_lds));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_k1p_replay, dim3((pl->total_chunks + 64 * replay_waves - 1) / (64 * replay_waves)), dim3(64 * replay_waves),
+    hipLaunchKernelGGL(replay, dim3((pl->total_chunks + 64 * replay_waves - 1) / (64 * replay_waves)), dim3(64 * replay_waves),
                        replay_lds, s, p, pl->total_chunks, reinterpret_cast<const uint32_t *>(est), res, status, stretch, max_stretch);
     return hipGetLastError();
 }
@@ -1071,7 +1098,7 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
 // `have` != nullptr: the stretch summaries (phase B1) have been made already, by k_k1p_replay.
 static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, const avr_chunk_plan *pl, uint8_t *w,
                               const uint8_t *res, uint32_t max_stretch, uint8_t *out, const uint64_t *out_off,
-                              uint32_t *out_len, int32_t *status, const Stretch *have = nullptr) {
+                              uint32_t *out_len, int32_t *status, const Stretch *have = nullptr, bool tile_codes = false) {
     Stretch *st_own = reinterpret_cast<Stretch *>(w);        w += up256(uint64_t(pl->total_chunks) * sizeof(Stretch));
     const Stretch *st = have ? have : st_own;
     Entry *en = reinterpret_cast<Entry *>(w);                w += up256(uint64_t(pl->total_chunks) * sizeof(Entry));
@@ -1080,7 +1107,8 @@ static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, c
     const uint32_t chunk_blocks = (pl->total_chunks + 255) / 256;
     if (!have) hipLaunchKernelGGL(k_k1p_b1, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, status, st_own, max_stretch);
     hipLaunchKernelGGL(k_k1p_b2, dim3(n_slices), dim3(256), 0, s, p, status, st, en, tot, S);
-    hipLaunchKernelGGL(k_k1p_c, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
+    if (tile_codes) hipLaunchKernelGGL(k_k1p_c<true>, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
+    else hipLaunchKernelGGL(k_k1p_c<false>, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
     uint32_t force_retry_every = 0;                              // test switch, see k_k1p_d
     if (const char *f = getenv("AVR_K1P_FORCE_RETRY")) force_retry_every = uint32_t(strtoul(f, nullptr, 10));
     hipLaunchKernelGGL(k_k1p_d, dim3(n_slices), dim3(256), 0, s, p, tot, S, out, out_off, out_len, status, force_retry_every);
@@ -1106,8 +1134,13 @@ static inline uint64_t resolve_ws_bytes(size_t n_slices, uint32_t n_states, cons
 }
 
 size_t k1p_code_workspace_bytes(size_t n_slices, const avr_chunk_plan *pl);
+// the code buffer between the two stages of launch_k1p: interleaved by tiles of 64 chunks (TileCodes)
+static inline uint64_t codes_bytes(const avr_chunk_plan *pl) {
+    const uint64_t tiled = tile_codes_bytes(pl->total_chunks), linear = pl->res_total + 32;
+    return tiled > linear ? tiled : linear;
+}
 size_t k1p_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_plan *pl) {
-    return size_t(up256(pl->res_total + 32) + resolve_ws_bytes(n_slices, n_states, pl)) + k1p_code_workspace_bytes(n_slices, pl);
+    return size_t(up256(codes_bytes(pl)) + resolve_ws_bytes(n_slices, n_states, pl)) + k1p_code_workspace_bytes(n_slices, pl);
 }
 
 constexpr uint32_t kK1pCensusStride = 16;
@@ -1123,11 +1156,12 @@ static hipError_t k1p_pass(hipStream_t s, const Plan &p, uint32_t n_slices, cons
                            int32_t *status, uint8_t *final_states, const DenseHint *hint, uint32_t stride, bool second_pass,
                            uint32_t *retry_count) {
     const Stretch *st = nullptr;
+    // the codes between the two stages stay inside this call: wave-interleaved (TileCodes)
     hipError_t e = launch_resolve(s, p, n_slices, init_states, pl, w, res, status, final_states, kMaxStretch, &st, hint, stride, second_pass,
-                                  retry_count);
+                                  retry_count, true);
     if (e != hipSuccess) return e;
     w += resolve_ws_bytes(n_slices, n_states, pl);
-    e = launch_code(s, p, n_slices, pl, w, res, kMaxStretch, out, out_off, out_len, status, st);
+    e = launch_code(s, p, n_slices, pl, w, res, kMaxStretch, out, out_off, out_len, status, st, true);
     if (e != hipSuccess) return e;
     // slices the scheme declined (status AVR_SLICE_RETRY_SERIAL) are coded by the serial kernel
     return launch_cabac_encode(false, s, p.recs, p.rec_off, p.n_bins, nullptr, n_slices, init_states, n_states, out, out_off,
@@ -1155,7 +1189,7 @@ hipError_t launch_k1p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
                       uint8_t *final_states, const DenseHint *hint) {
     if (n_slices == 0) return hipSuccess;
     uint8_t *w = static_cast<uint8_t *>(workspace);
-    uint8_t *res = w;                                        w += up256(pl->res_total + 32);
+    uint8_t *res = w;                                        w += up256(codes_bytes(pl));
     const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
                  pl->dig_off, 0, n_states, nullptr, nullptr};
     const uint32_t stride = census_stride();
@@ -1173,7 +1207,7 @@ hipError_t launch_k1p_retry(hipStream_t s, const uint16_t *recs, const uint64_t 
                             uint8_t *final_states) {
     if (n_slices == 0) return hipSuccess;
     uint8_t *w = static_cast<uint8_t *>(workspace);
-    uint8_t *res = w;                                        w += up256(pl->res_total + 32);
+    uint8_t *res = w;                                        w += up256(codes_bytes(pl));
     const Plan p{recs, rec_off, n_bins, pl->res_off, pl->chunk_base, pl->chunk_slice, pl->blk_base, pl->blk_slice,
                  pl->dig_off, 0, n_states, nullptr, nullptr};
     return k1p_second_pass(s, p, n_slices, init_states, n_states, pl, w, res, out, out_off, out_len, status, final_states, true);
