@@ -365,3 +365,31 @@ def test_batch_submit_wait_codes_and_range(avr, oracle):
         b.wait()
         for i, r in enumerate(ranges):
             assert b.get(i) == oracle.range_encode(r), f"K2 slice {i}"
+
+
+def test_batch_second_pass_from_wait(avr, oracle):
+    """Few long slices, one of them with single bins in contexts nobody else uses: the sampled census misses them, the
+    chunk sort sets the slice aside, and it takes the second pass -- inside the run when the run asks the device for the
+    context count (first run of a batch object), from avr_batch_wait when the run was sized by a guess (second run)."""
+    rng = np.random.default_rng(31)
+    ns = 200
+    slices = []
+    for i in range(5):
+        r, s = oracle_lib.random_cabac_stream(rng, 30000 + 3000 * i, 50)
+        slices.append((r, np.concatenate([s, rng.integers(0, 126, ns - 50).astype(np.uint8)])))
+    slices[3][0][12345] = np.uint16((199 << 1) | 1)
+    slices[3][0][20001] = np.uint16((77 << 1) | 0)
+    with avr.Batch(0, 8, 400000) as b:
+        for r, s in slices:
+            b.add_slice_cabac(r, s)
+        for run in range(2):
+            b.submit()
+            b.wait()
+            info = b.run_info()
+            assert info["chunked"] == 1
+            assert (info["rows_guessed"] > 0) == (run == 1)
+            if run == 1:
+                assert info["ran_again"] & 2               # the second pass came from avr_batch_wait
+            for i, (r, s) in enumerate(slices):
+                data, status = b.get(i)
+                assert (data, b.get_states(i), status) == oracle.cabac_encode(r, s), f"run {run} slice {i}"
