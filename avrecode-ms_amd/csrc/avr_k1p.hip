@@ -429,6 +429,8 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
 }
 
 __device__ __forceinline__ CodeEntry device_code_entry(uint32_t c);
+// per code: { low byte of rLPS << shift per range quarter, the shift per quarter } (see step_pair)
+__device__ __forceinline__ uint2 device_codes2(uint32_t c);
 
 // Replay + phase B1: one lane per chunk, its records in stream order.  est[gc][k] is the state of context k
 // when the chunk is entered, so a lane loads those states (one byte per context, in LDS, laid out (k, lane)
@@ -468,6 +470,98 @@ __device__ __forceinline__ uint32_t step_pair(uint32_t &Rp, uint32_t row, uint32
     return (sym ? shl : shm) + extra;
 }
 
+// Phase B1 as the kernels walk it (the logic of b1_stretch, avr_k1p.h, which stays the CPU's statement of it): a chunk's
+// stretch summary from its bins in order, eight at a time.  A bin comes as the table entry { x: LPS ranges of its state's
+// four range quarters, y: (code << 8) | (meta << 16) } (k_k1p_replay has it from its state look-up, k_k1p_b1 from the code).
+// mode: 0 = looking for the LPS that opens the stretch, 1 = four candidate ranges, 2 = they have met, 3 = closed.
+struct B1Walk {
+    uint32_t i0, i1, limit, n, max_stretch;
+    const uint2 *codes2;
+    uint32_t mode, Rp0, Rp1, Tp0, Tp1, T[4], Rm, Tm, end;  // candidates 0, 1 in Rp0 (low, high half), 2, 3 in Rp1; Tp: their shifts since the last flush
+    bool merged;
+    Stretch o;
+
+    __device__ __forceinline__ void init(uint32_t chunk, uint32_t i0_, uint32_t i1_, uint32_t n_, uint32_t max_stretch_, const uint2 *codes2_) {
+        i0 = i0_; i1 = i1_; limit = i0_ + kChunk; n = n_; max_stretch = max_stretch_; codes2 = codes2_;
+        mode = 0; Rp0 = Rp1 = 0x01fe01feu; Tp0 = Tp1 = 0; T[0] = T[1] = T[2] = T[3] = 0; Rm = 510; Tm = 0; end = 0;
+        merged = false;
+        o.first = kNone; o.end = 0; o.exit_q = 0; o.too_long = 0; o.pad[0] = o.pad[1] = 0;
+        for (int q = 0; q < 4; q++) { o.t_exit[q] = 0; o.r_exit[q] = 0; }
+        if (chunk == 0) { o.first = 0; mode = 2; merged = true; }    // opens at bin 0 with the initial range 510 (cabac_code.h:30)
+    }
+    __device__ __forceinline__ void flush_t() {                  // at least every 8 bins: 8 x 9 shifts fit 16 bits with room
+        T[0] += Tp0 & 0xffffu; T[1] += Tp0 >> 16; T[2] += Tp1 & 0xffffu; T[3] += Tp1 >> 16;
+        Tp0 = Tp1 = 0;
+    }
+    __device__ __forceinline__ bool met() const { return Rp0 == Rp1 && (Rp0 >> 16) == (Rp0 & 0xffffu); }
+    __device__ __forceinline__ void one(uint32_t idx, const uint2 &e) {       // bin idx (< n), any mode
+        const CodeEntry ce{e.x, e.y >> 16};
+        const bool boundary = ce.meta & 1u;                      // a coded LPS (code_is_boundary)
+        if (mode == 0) {
+            if (idx < i1 && boundary) {
+                o.first = idx;
+                const uint32_t rown = codes2[(e.y >> 8) & 0xffu].x;              // post_lps_range for the four quarters
+                Rp0 = __builtin_amdgcn_perm(rown, rown, 0x0c010c00u) | 0x01000100u;
+                Rp1 = __builtin_amdgcn_perm(rown, rown, 0x0c030c02u) | 0x01000100u;
+                mode = 1;
+            }
+        } else if (mode == 1) {
+            const bool closing = idx >= limit && boundary;
+            if (closing)
+                o.exit_q |= uint8_t(((Rp0 >> 6) & 3u) | ((Rp0 >> 22) & 3u) << 2 | ((Rp1 >> 6) & 3u) << 4 | ((Rp1 >> 22) & 3u) << 6);
+            const uint2 e2 = codes2[(e.y >> 8) & 0xffu];
+            const uint32_t extra = (ce.meta >> 8) * 0x00010001u;                 // a bypass bin's one shift
+            Tp0 = pk_add(Tp0, step_pair(Rp0, ce.row, e2.x, e2.y, boundary, extra));
+            Tp1 = pk_add(Tp1, step_pair(Rp1, ce.row, e2.x, e2.y, boundary, extra));
+            if (closing) { end = idx + 1; mode = 3; }
+            else if (met()) { Rm = Rp0 & 0xffffu; mode = 2; merged = true; }
+        } else if (mode == 2) {
+            const bool closing = idx >= limit && boundary;
+            if (closing) o.exit_q = uint8_t(((Rm >> 6) & 3) * 0x55u);
+            Tm += step_range(ce, &Rm);
+            if (closing) { end = idx + 1; mode = 3; }
+            else if (idx >= limit && idx - i0 > max_stretch) { o.too_long = 1; end = idx + 1; mode = 3; }
+        }
+    }
+    __device__ __forceinline__ void group(uint32_t base, const uint2 e[8]) {  // bins base .. base+7
+        if (mode == 2 && base + 8 <= i1) {                       // merged and inside the chunk: nothing can close the stretch
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) { const CodeEntry ce{e[j].x, e[j].y >> 16}; Tm += step_range(ce, &Rm); }
+        } else if (mode == 1 && base + 8 <= i1) {                // four candidates, inside the chunk: the same, and no branch per bin
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint2 e2 = codes2[(e[j].y >> 8) & 0xffu];
+                const bool sym = (e[j].y >> 16) & 1u;
+                const uint32_t extra = (e[j].y >> 24) * 0x00010001u;
+                Tp0 = pk_add(Tp0, step_pair(Rp0, e[j].x, e2.x, e2.y, sym, extra));
+                Tp1 = pk_add(Tp1, step_pair(Rp1, e[j].x, e2.x, e2.y, sym, extra));
+            }
+            flush_t();
+            // candidates that have met stay together: looking once per group is enough, and the group's shifts are in T[] either way
+            if (met()) { Rm = Rp0 & 0xffffu; mode = 2; merged = true; }
+        } else if (mode != 3) {
+            for (uint32_t j = 0; j < 8; j++) if (base + j < n) one(base + j, e[j]);
+            flush_t();
+        }
+    }
+    __device__ __forceinline__ void chunk_done() { if (mode == 0) mode = 3; }  // no LPS in the chunk: no stretch opens here (first stays kNone)
+    __device__ __forceinline__ void tail(uint32_t base, const uint2 e[8]) {      // past the chunk, until the stretch closes
+        for (uint32_t j = 0; j < 8; j++) if (base + j < n && mode != 3) one(base + j, e[j]);
+        flush_t();
+    }
+    __device__ __forceinline__ const Stretch &finish() {
+        if (o.first != kNone) {
+            o.end = mode != 3 ? n : end;                         // not closed: ran to the end of the slice
+            for (uint32_t q = 0; q < 4; q++) {                   // once merged, Rm / Tm carried on for all four candidates
+                const uint32_t rq = ((q & 2u) ? Rp1 : Rp0) >> (16 * (q & 1u)) & 0xffffu;
+                o.t_exit[q] = T[q] + (merged ? Tm : 0u);
+                o.r_exit[q] = uint16_t(merged ? Rm : rq);
+            }
+        }
+        return o;
+    }
+};
+
 template <bool TILE_CODES>
 __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *est, uint8_t *res,
                                                     const int32_t *status, Stretch *stretch, uint32_t max_stretch) {
@@ -476,15 +570,7 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
     __shared__ uint2 codes2[256];
     __shared__ uint32_t sel_off[2048];
     const uint32_t lane = threadIdx.x & 63, nk = p.n_states;
-    for (uint32_t c = threadIdx.x; c < 256; c += blockDim.x) {
-        const uint32_t row = device_code_entry(c).row;
-        uint32_t rown = 0, shrow = 0;
-        for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t rl = (row >> (8 * q)) & 0xffu;
-            if (rl) { uint32_t sh; const uint32_t rn = post_lps_range(row, q, &sh); rown |= (rn & 0xffu) << (8 * q); shrow |= sh << (8 * q); }
-        }
-        codes2[c] = make_uint2(rown, shrow);
-    }
+    for (uint32_t c = threadIdx.x; c < 256; c += blockDim.x) codes2[c] = device_codes2(c);
     uint8_t *stb = reinterpret_cast<uint8_t *>(replay_lds) + (threadIdx.x >> 6) * (((nk + 8) >> 2) << 8) + lane * 4;
     for (uint32_t sel = threadIdx.x; sel < 2048; sel += blockDim.x) {
         // contexts get their dense id; 1024 (bypass), 1025 (terminate), 1026 (no-op) -> nk+1, nk+2, nk+3; the rest nk / nk+4
@@ -533,46 +619,8 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
         if (TILE_CODES) *reinterpret_cast<U4 *>(ro + size_t((i - i0) >> 4) * 1024) = v;
         else *reinterpret_cast<U4 *>(ro + i) = v;
     };
-    // ---- B1 (the logic of b1_stretch): 0 = looking for the LPS that opens the stretch, 1 = four candidate ranges,
-    // 2 = they have merged, 3 = closed
-    const uint32_t limit = i0 + kChunk;
-    // candidates 0, 1 in Rp0 (low, high half), 2, 3 in Rp1; Tp0 / Tp1: their shifts since the last flush into T[]
-    uint32_t mode = 0, Rp0 = 0x01fe01feu, Rp1 = 0x01fe01feu, Tp0 = 0, Tp1 = 0, T[4] = {0, 0, 0, 0}, Rm = 510, Tm = 0, end = 0;
-    bool merged = false;
-    if (c == 0) { o.first = 0; mode = 2; merged = true; }        // opens at bin 0 with the initial range 510 (cabac_code.h:30)
-    auto flush_t = [&]() {                                       // at least every 8 bins: 8 x 9 shifts fit 16 bits with room
-        T[0] += Tp0 & 0xffffu; T[1] += Tp0 >> 16; T[2] += Tp1 & 0xffffu; T[3] += Tp1 >> 16;
-        Tp0 = Tp1 = 0;
-    };
-    auto one = [&](uint32_t idx, const uint2 &e) {               // bin idx (< n) with table entry e, any mode
-        const CodeEntry ce{e.x, e.y >> 16};
-        const bool boundary = ce.meta & 1u;                      // a coded LPS (code_is_boundary)
-        if (mode == 0) {
-            if (idx < i1 && boundary) {
-                o.first = idx;
-                const uint32_t rown = codes2[(e.y >> 8) & 0xffu].x;              // post_lps_range for the four quarters
-                Rp0 = __builtin_amdgcn_perm(rown, rown, 0x0c010c00u) | 0x01000100u;
-                Rp1 = __builtin_amdgcn_perm(rown, rown, 0x0c030c02u) | 0x01000100u;
-                mode = 1;
-            }
-        } else if (mode == 1) {
-            const bool closing = idx >= limit && boundary;
-            if (closing)
-                o.exit_q |= uint8_t(((Rp0 >> 6) & 3u) | ((Rp0 >> 22) & 3u) << 2 | ((Rp1 >> 6) & 3u) << 4 | ((Rp1 >> 22) & 3u) << 6);
-            const uint2 e2 = codes2[(e.y >> 8) & 0xffu];
-            const uint32_t extra = (ce.meta >> 8) * 0x00010001u;                 // a bypass bin's one shift
-            Tp0 = pk_add(Tp0, step_pair(Rp0, ce.row, e2.x, e2.y, boundary, extra));
-            Tp1 = pk_add(Tp1, step_pair(Rp1, ce.row, e2.x, e2.y, boundary, extra));
-            if (closing) { end = idx + 1; mode = 3; }
-            else if (Rp0 == Rp1 && (Rp0 >> 16) == (Rp0 & 0xffffu)) { Rm = Rp0 & 0xffffu; mode = 2; merged = true; }
-        } else if (mode == 2) {
-            const bool closing = idx >= limit && boundary;
-            if (closing) o.exit_q = uint8_t(((Rm >> 6) & 3) * 0x55u);
-            Tm += step_range(ce, &Rm);
-            if (closing) { end = idx + 1; mode = 3; }
-            else if (idx >= limit && idx - i0 > max_stretch) { o.too_long = 1; end = idx + 1; mode = 3; }
-        }
-    };
+    B1Walk b1;
+    b1.init(c, i0, i1, n, max_stretch, codes2);
     // 8 records (16 bytes) -> 8 codes; e[] = their table entries
     auto eight = [&](const U4 &v, uint32_t &c0, uint32_t &c1, uint2 e[8]) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -591,27 +639,6 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
         }
         c0 = cc[0]; c1 = cc[1];
     };
-    auto b1_group = [&](uint32_t base, const uint2 e[8]) {       // bins base .. base+7
-        if (mode == 2 && base + 8 <= i1) {                       // merged and inside the chunk: nothing can close the stretch
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) { const CodeEntry ce{e[j].x, e[j].y >> 16}; Tm += step_range(ce, &Rm); }
-        } else if (mode == 1 && base + 8 <= i1) {                // four candidates, inside the chunk: the same, and no branch per bin
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) {
-                const uint2 e2 = codes2[(e[j].y >> 8) & 0xffu];
-                const bool sym = (e[j].y >> 16) & 1u;
-                const uint32_t extra = (e[j].y >> 24) * 0x00010001u;
-                Tp0 = pk_add(Tp0, step_pair(Rp0, e[j].x, e2.x, e2.y, sym, extra));
-                Tp1 = pk_add(Tp1, step_pair(Rp1, e[j].x, e2.x, e2.y, sym, extra));
-            }
-            flush_t();
-            // candidates that have met stay together: looking once per group is enough, and the group's shifts are in T[] either way
-            if (Rp0 == Rp1 && (Rp0 >> 16) == (Rp0 & 0xffffu)) { Rm = Rp0 & 0xffffu; mode = 2; merged = true; }
-        } else if (mode != 3) {
-            for (uint32_t j = 0; j < 8; j++) if (base + j < n) one(base + j, e[j]);
-            flush_t();
-        }
-    };
     // a slice's records are padded with no-ops to a multiple of 8, its codes to a multiple of 16
     uint32_t i = i0;
     if (i0 < n) {
@@ -628,10 +655,10 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
             }
             U4 a, b;
             uint2 e[8];
-            eight(v0, a.x, a.y, e); b1_group(i, e);
-            eight(v1, a.z, a.w, e); b1_group(i + 8, e);
-            eight(v2, b.x, b.y, e); b1_group(i + 16, e);
-            eight(v3, b.z, b.w, e); b1_group(i + 24, e);
+            eight(v0, a.x, a.y, e); b1.group(i, e);
+            eight(v1, a.z, a.w, e); b1.group(i + 8, e);
+            eight(v2, b.x, b.y, e); b1.group(i + 16, e);
+            eight(v3, b.z, b.w, e); b1.group(i + 24, e);
             put16(i, a);
             put16(i + 16, b);
             v0 = n0; v1 = n1; v2 = n2; v3 = n3;
@@ -642,29 +669,20 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
             const U4 t0 = q[0], t1 = i + 8 < i1 ? q[1] : nop;
             U4 a;
             uint2 e[8];
-            eight(t0, a.x, a.y, e); b1_group(i, e);
-            eight(t1, a.z, a.w, e); b1_group(i + 8, e);
+            eight(t0, a.x, a.y, e); b1.group(i, e);
+            eight(t1, a.z, a.w, e); b1.group(i + 8, e);
             put16(i, a);
         }
-        if (mode == 0) mode = 3;                                 // no LPS in the chunk: no stretch opens here (first stays kNone)
+        b1.chunk_done();
         // past the chunk: on through the next chunk's bins until the stretch closes (codes not written: not this lane's)
-        for (i = limit; mode != 3 && i < n; i += 8) {
+        for (i = i0 + kChunk; b1.mode != 3 && i < n; i += 8) {
             uint32_t c0, c1;
             uint2 e[8];
             eight(*reinterpret_cast<const U4 *>(r + i), c0, c1, e);
-            for (uint32_t j = 0; j < 8; j++) if (i + j < n && mode != 3) one(i + j, e[j]);
-            flush_t();
+            b1.tail(i, e);
         }
     }
-    if (o.first != kNone) {
-        o.end = mode != 3 ? n : end;                             // not closed: ran to the end of the slice
-        for (uint32_t q = 0; q < 4; q++) {                       // once merged, Rm / Tm carried on for all four candidates
-            const uint32_t rq = ((q & 2u) ? Rp1 : Rp0) >> (16 * (q & 1u)) & 0xffffu;
-            o.t_exit[q] = T[q] + (merged ? Tm : 0u);
-            o.r_exit[q] = uint16_t(merged ? Rm : rq);
-        }
-    }
-    stretch[gc] = o;
+    stretch[gc] = b1.finish();
 }
 
 // ------------------------------------------------------------------ phases B1, B2, C
@@ -675,18 +693,67 @@ __device__ __forceinline__ CodeEntry device_code_entry(uint32_t c) {
     return CodeEntry{d_tables.packed[2 * (c >> 2)][0], code_sym(c) * 3u};
 }
 
+__device__ __forceinline__ uint2 device_codes2(uint32_t c) {
+    const uint32_t row = device_code_entry(c).row;
+    uint32_t rown = 0, shrow = 0;
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t rl = (row >> (8 * q)) & 0xffu;
+        if (rl) { uint32_t sh; const uint32_t rn = post_lps_range(row, q, &sh); rown |= (rn & 0xffu) << (8 * q); shrow |= sh << (8 * q); }
+    }
+    return make_uint2(rown, shrow);
+}
+
+// Phase B1 from finished codes (the resolved-code entry points; k_k1p_replay does the same walk on the fly): one lane per
+// chunk, a cache line of codes per trip with the next one in flight, eight codes to a group of B1Walk.
 __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, const uint8_t *res,
                                                 const int32_t *status, Stretch *st, uint32_t max_stretch) {
-    __shared__ CodeEntry codes[256];
-    codes[threadIdx.x] = device_code_entry(threadIdx.x);
+    __shared__ uint2 cinfo[256];                                 // per code: { LPS ranges of its state, (code << 8) | (meta << 16) }
+    __shared__ uint2 codes2[256];
+    {
+        const CodeEntry ce = device_code_entry(threadIdx.x);
+        cinfo[threadIdx.x] = make_uint2(ce.row, threadIdx.x << 8 | ce.meta << 16);
+        codes2[threadIdx.x] = device_codes2(threadIdx.x);
+    }
     __syncthreads();
     const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
     if (gc >= total_chunks) return;
     const uint32_t slice = p.chunk_slice[gc];
     if (status[slice] != AVR_SLICE_OK) { st[gc].first = kNone; st[gc].too_long = 0; return; }
-    Stretch o;
-    b1_stretch(res + p.res_off[slice], p.n_bins[slice], gc - p.chunk_base[slice], codes, max_stretch, &o);
-    st[gc] = o;
+    const uint32_t c = gc - p.chunk_base[slice], n = p.n_bins[slice], i0 = c * kChunk;
+    const uint32_t i1 = i0 + kChunk < n ? i0 + kChunk : n;
+    const uint8_t *r = res + p.res_off[slice];
+    B1Walk b1;
+    b1.init(c, i0, i1, n, max_stretch, codes2);
+    auto eight = [&](uint32_t lo, uint32_t hi, uint2 e[8]) {     // eight codes, first in lo's low byte
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) e[j] = cinfo[((j < 4 ? lo : hi) >> (8 * (j & 3))) & 0xffu];
+    };
+    auto sixteen = [&](uint32_t base, const U4 &v) {
+        uint2 e[8];
+        eight(v.x, v.y, e); b1.group(base, e);
+        eight(v.z, v.w, e); b1.group(base + 8, e);
+    };
+    // a slice's codes are padded to a multiple of 16 (with a group to spare): whole 16-byte loads up to the padded end
+    uint32_t i = i0;
+    if (i0 < n) {
+        U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+        if (i + 64 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i); v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
+        for (; i + 64 <= i1; i += 64) {
+            U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
+            if (i + 128 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i + 64); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+            sixteen(i, v0); sixteen(i + 16, v1); sixteen(i + 32, v2); sixteen(i + 48, v3);
+            v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+        }
+        for (; i < i1; i += 16) sixteen(i, *reinterpret_cast<const U4 *>(r + i));
+        b1.chunk_done();
+        for (i = i0 + kChunk; b1.mode != 3 && i < n; i += 16) {  // past the chunk, until the stretch closes
+            const U4 v = *reinterpret_cast<const U4 *>(r + i);
+            uint2 e[8];
+            eight(v.x, v.y, e); b1.tail(i, e);
+            if (b1.mode != 3) { eight(v.z, v.w, e); b1.tail(i + 8, e); }
+        }
+    }
+    st[gc] = b1.finish();
 }
 
 // One workgroup per slice: the stretch summaries are staged through LDS a tile at a time (coalesced),
