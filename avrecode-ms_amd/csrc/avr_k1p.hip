@@ -705,8 +705,9 @@ __device__ __forceinline__ uint2 device_codes2(uint32_t c) {
 
 // Phase B1 from finished codes (the resolved-code entry points; k_k1p_replay does the same walk on the fly): one lane per
 // chunk, a cache line of codes per trip with the next one in flight, eight codes to a group of B1Walk.
+// `tile` != null: the chunk's codes are also written there wave-interleaved (TileCodes), for phase C to read.
 __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, const uint8_t *res,
-                                                const int32_t *status, Stretch *st, uint32_t max_stretch) {
+                                                const int32_t *status, Stretch *st, uint32_t max_stretch, uint8_t *tile) {
     __shared__ uint2 cinfo[256];                                 // per code: { LPS ranges of its state, (code << 8) | (meta << 16) }
     __shared__ uint2 codes2[256];
     {
@@ -728,7 +729,9 @@ __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, c
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++) e[j] = cinfo[((j < 4 ? lo : hi) >> (8 * (j & 3))) & 0xffu];
     };
+    uint8_t *to = tile ? tile + ((size_t(gc >> 6) * 64) * 64 + (gc & 63u)) * 16 : nullptr;
     auto sixteen = [&](uint32_t base, const U4 &v) {
+        if (to) *reinterpret_cast<U4 *>(to + size_t((base - i0) >> 4) * 1024) = v;
         uint2 e[8];
         eight(v.x, v.y, e); b1.group(base, e);
         eight(v.z, v.w, e); b1.group(base + 8, e);
@@ -1170,9 +1173,15 @@ static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, c
     const Stretch *st = have ? have : st_own;
     Entry *en = reinterpret_cast<Entry *>(w);                w += up256(uint64_t(pl->total_chunks) * sizeof(Entry));
     SliceTotals *tot = reinterpret_cast<SliceTotals *>(w);   w += up256(n_slices * sizeof(SliceTotals));
-    uint32_t *S = reinterpret_cast<uint32_t *>(w);
+    uint32_t *S = reinterpret_cast<uint32_t *>(w);               w += up256(pl->dig_total * 4 + 16);
     const uint32_t chunk_blocks = (pl->total_chunks + 255) / 256;
-    if (!have) hipLaunchKernelGGL(k_k1p_b1, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, status, st_own, max_stretch);
+    if (!have) {
+        // codes from the caller, slice-major: B1 reads them lane by lane once and leaves a wave-interleaved copy for phase C
+        uint8_t *tile = w;
+        hipLaunchKernelGGL(k_k1p_b1, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, status, st_own, max_stretch, tile);
+        res = tile;
+        tile_codes = true;
+    }
     hipLaunchKernelGGL(k_k1p_b2, dim3(n_slices), dim3(256), 0, s, p, status, st, en, tot, S);
     if (tile_codes) hipLaunchKernelGGL(k_k1p_c<true>, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
     else hipLaunchKernelGGL(k_k1p_c<false>, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
@@ -1302,7 +1311,7 @@ hipError_t launch_k1p_resolve(hipStream_t s, const uint16_t *recs, const uint64_
 // LPS is simply walked to its end by one lane); a slice phase D hands back is coded by k_cabac_encode_codes
 size_t k1p_code_workspace_bytes(size_t n_slices, const avr_chunk_plan *pl) {
     return size_t(up256(uint64_t(pl->total_chunks) * sizeof(Stretch)) + up256(uint64_t(pl->total_chunks) * sizeof(Entry)) +
-                  up256(n_slices * sizeof(SliceTotals)) + up256(pl->dig_total * 4 + 16));
+                  up256(n_slices * sizeof(SliceTotals)) + up256(pl->dig_total * 4 + 16) + up256(tile_codes_bytes(pl->total_chunks)));
 }
 hipError_t launch_k1p_code(hipStream_t s, const uint8_t *codes, const uint32_t *n_bins, uint32_t n_slices,
                            const avr_chunk_plan *pl, void *workspace, uint8_t *out, const uint64_t *out_off,
