@@ -355,7 +355,36 @@ def test_batch_submit_wait_in_turn(avr, oracle):
 
 
 def test_batch_submit_wait_codes_and_range(avr, oracle):
+    """The other two kinds through submit / wait and the zero-copy add: K2 records, and resolved codes (made here from
+    records the way a recorder that tracks *state would: AVR_CODE_* of include/avrecode_ms_amd.h) in both shapes of
+    batch -- many short slices (one lane per slice) and few long ones (phases B-D of the chunked path)."""
     rng = np.random.default_rng(5)
+    _, mlps = avr.cabac_tables()
+    mlps = np.frombuffer(mlps, np.uint8)
+
+    def resolve(r, states):
+        state = [int(x) for x in states]
+        out = np.empty(len(r), np.uint8)
+        for j, rec in enumerate(r.tolist()):
+            b_, sel = rec & 1, rec >> 1
+            if sel < 1024:
+                s_ = state[sel]
+                out[j] = 255 - ((b_ ^ s_) & 1) if s_ >= 126 else (s_ << 1) | b_
+                state[sel] = int(mlps[127 - s_] if b_ != (s_ & 1) else mlps[128 + s_])
+            else:
+                out[j] = (252 | b_) if sel == 1024 else 255 - b_
+        return out
+    for lengths in ([int(rng.integers(0, 800)) for _ in range(60)], [9000, 12000, 17000]):
+        streams = [oracle_lib.random_cabac_stream(rng, n, 40) for n in lengths]
+        with avr.Batch(0, 100, 200000) as b:
+            for r, s in streams:
+                _, view = b.reserve(avr.KIND_CABAC_CODES, len(r))
+                view[:] = resolve(r, s)
+            b.submit()
+            b.wait()
+            for i, (r, s) in enumerate(streams):
+                data, status = b.get(i)
+                assert (data, status) == (oracle.cabac_encode(r, s)[0], 0), f"codes slice {i} n={len(r)}"
     ranges = [oracle_lib.random_range_stream(rng, int(rng.integers(0, 1500))) for _ in range(70)]
     with avr.Batch(0, 100, 200000) as b:
         for r in ranges:
