@@ -20,6 +20,7 @@ import ctypes
 import os
 import shutil
 import subprocess
+import sys
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -256,7 +257,10 @@ class Batch:
             self._L.avr_batch_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        # at interpreter shutdown the HIP runtime may be gone already: its own teardown frees what is left
+        if not sys.is_finalizing():
+            self.close()
 
     def __enter__(self):
         return self
@@ -344,7 +348,9 @@ class MultiBatch:
             self._L.avr_multi_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        if not sys.is_finalizing():
+            self.close()
 
     def __enter__(self):
         return self
