@@ -29,6 +29,7 @@ def short(name):
     return name.split("(")[0].replace("void ", "").replace("avr::", "")
 
 
+SQ_STEPS = 2         # ... and the SQ counter pass with --steps 1 --warmup 1
 PMC_STEPS = 4        # tools/gpu_final.sh runs the counter passes with --steps 3 --warmup 1: four identical steps
 
 
@@ -77,7 +78,7 @@ for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches o
         wr = csv.writer(f)
         wr.writerow(["kernel"] + names)
         for k in sorted({k[0] for k in agg}):
-            wr.writerow([k] + ["%.6g" % (agg[(k, c)] / max(cnt[(k, c)], 1)) for c in names])
+            wr.writerow([k] + ["%.6g" % (agg[(k, c)] / SQ_STEPS) for c in names])   # per step: all launches of the run / its steps
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
 for b in ("w2", "w3", "w4", "w5", "w5_k2", "w2_resolved", "w2_k2", "w4_k2"):
