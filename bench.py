@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 DEFAULT_SLICES = {2: 512, 3: 4096, 4: 16384, 5: 1 << 20}
 WORKLOAD_NAME = {
-    2: "config2: 1080p30 CABAC clip, 1 slice/frame, 512 frames (synthetic, 8160 MB/slice)",
+    2: "config2: 1080p30 CABAC clip, 1 slice/frame, 512 frames (synthetic, 8160 macroblocks per slice)",
     3: "config3: 16 files x 256 slices, log-normal slice sizes (synthetic)",
     4: "config4: 4K60, 8 slices/frame, 16384 slices (synthetic, 4080 MB/slice)",
     5: "config5: residual-only streams, 1M slices x 64 4x4 blocks (synthetic)",
