@@ -762,13 +762,14 @@ __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, c
 // One workgroup per slice: the stretch summaries are staged through LDS a tile at a time (coalesced),
 // thread 0 runs the serial 4->4 chain on them (b2_chain's loop, fed from LDS instead of ~600
 // dependent trips to HBM), and the entries go back out coalesced.
-constexpr uint32_t kB2Tile = 1024;
+constexpr uint32_t kB2Tile = 1024, kB2Seg = 16;                  // kB2Tile / kB2Seg segments x 4 quarters = the workgroup's 256 threads
 
 __global__ __launch_bounds__(256) void k_k1p_b2(Plan p, const int32_t *status, const Stretch *st, Entry *en,
                                                 SliceTotals *tot, uint32_t *S) {
     __shared__ Stretch tile[kB2Tile];
     __shared__ Entry ent[kB2Tile];
     __shared__ uint8_t xq[kB2Tile], qin[kB2Tile];               // exit quarter per entry quarter (2 bits each); entry quarter
+    __shared__ uint8_t segmap[256], segin[kB2Tile / kB2Seg];     // per segment of kB2Seg stretches: exit quarter per entry quarter; entry quarter
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t carry[4];                                // T, q, r, bad across tiles
     const uint32_t s = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -787,10 +788,25 @@ __global__ __launch_bounds__(256) void k_k1p_b2(Plan p, const int32_t *status, c
         // the only serial part is the quarter: one byte look-up per stretch (an inactive chunk maps q to q)
         for (uint32_t c = t; c < kB2Tile; c += 256) xq[c] = c < cnt && tile[c].first != kNone ? tile[c].exit_q : uint8_t(0xE4);
         __syncthreads();
+        // ... and that chain in three short legs instead of one long one: segments of 16 stretches are walked for each of
+        // the four entry quarters at once (thread = segment x quarter), one thread strings the 64 segment maps together,
+        // then every segment is walked again from its now known entry quarter: 16 + 64 + 16 dependent look-ups, not 1024.
+        {
+            const uint32_t seg = t >> 2, c_lo = seg * kB2Seg;
+            uint32_t q = t & 3u;
+            for (uint32_t c = c_lo; c < c_lo + kB2Seg; c++) q = (xq[c] >> (2 * q)) & 3;     // (past cnt: identity maps)
+            segmap[t] = uint8_t(q);
+        }
+        __syncthreads();
         if (t == 0) {
             uint32_t q = carry[1];
-            for (uint32_t c = 0; c < cnt; c++) { qin[c] = uint8_t(q); q = (xq[c] >> (2 * q)) & 3; }
-            carry[1] = q;
+            for (uint32_t sg = 0; sg < kB2Tile / kB2Seg; sg++) { segin[sg] = uint8_t(q); q = segmap[4 * sg + q]; }
+            carry[1] = q;                                        // identity past cnt: the quarter after the tile's last stretch
+        }
+        __syncthreads();
+        if (t < kB2Tile / kB2Seg) {
+            uint32_t q = segin[t];
+            for (uint32_t c = t * kB2Seg; c < (t + 1) * kB2Seg; c++) { qin[c] = uint8_t(q); q = (xq[c] >> (2 * q)) & 3; }
         }
         __syncthreads();
         // everything else follows from the entry quarters: shifts (prefix sum), range, flags.  Thread t
