@@ -159,6 +159,34 @@ def test_api_argument_errors(avr):
         assert b.timings()["encode_ms"] > 0
 
 
+def test_api_submit_wait_errors(avr):
+    """The order the pipelined calls must come in, and what each refuses."""
+    with avr.Batch(0, 4, 64) as b:
+        with pytest.raises(avr.AvrError, match="not been submitted"):
+            b.wait()
+        with pytest.raises(avr.AvrError, match="unknown kind"):
+            b.reserve(7, 4)
+        b.add_slice_cabac(np.array([TERM1]), np.zeros(8, dtype=np.uint8))
+        with pytest.raises(avr.AvrError, match="one kind"):
+            b.reserve(avr.KIND_RANGE, 4)
+        b.submit()
+        for call in (b.submit, b.reset, lambda: b.get(0), lambda: b.add_slice_cabac(np.array([TERM1]), np.zeros(8, dtype=np.uint8)),
+                     lambda: b.reserve(avr.KIND_CABAC, 1, np.zeros(8, dtype=np.uint8))):
+            with pytest.raises(avr.AvrError):
+                call()                                         # in flight: nothing but avr_batch_wait
+        b.wait()
+        b.wait()                                               # a second wait is a no-op
+        assert b.get(0)[0] == b"\xfe\x80"
+        with pytest.raises(avr.AvrError, match="already ran"):
+            b.run()                                            # avr_batch_run keeps its contract; submit may come again
+        b.submit()
+        b.wait()
+        assert b.get(0)[0] == b"\xfe\x80"
+    with avr.Batch(0, 4, 64) as b:                             # an empty batch goes through both calls
+        b.submit()
+        b.wait()
+
+
 # ------------------------------------------------------------------ synthetic workloads, device resident
 
 def host_synth(avr, workload, n_slices, kind, scale, first=0):
