@@ -34,8 +34,8 @@ SLICE_OK, SLICE_ZERO_PROB, SLICE_OVERFLOW, SLICE_BAD_RECORD = 0, 1, 2, 3
 NOP_CABAC, NOP_RANGE = 1026 << 1, 0
 CHUNK_BINS, SORT_BLOCK_BINS = 1024, 4096
 
-_SOURCES = ["avr_kernels.hip", "avr_k1p.hip", "avr_api.cpp"]
-_DEPS = _SOURCES + ["avr_coder.h", "avr_internal.h", "avr_k1p.h", "avr_synth.h", "avr_tables.h"]
+_SOURCES = ["avr_kernels.hip", "avr_k1p.hip", "avr_k2p.hip", "avr_api.cpp"]
+_DEPS = _SOURCES + ["avr_coder.h", "avr_div.h", "avr_internal.h", "avr_k1p.h", "avr_k2p.h", "avr_synth.h", "avr_tables.h"]
 
 
 class AvrError(RuntimeError):
@@ -143,6 +143,9 @@ SIGNATURES = {
     "avr_cabac_encode_chunked_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                                 c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_void_p]),
+    "avr_range_chunked_workspace_bytes": (c_size_t, [c_size_t, c_void_p, ctypes.c_uint64]),
+    "avr_range_encode_chunked_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,
+                                                c_void_p, c_void_p, ctypes.c_uint64, c_void_p, c_void_p]),
     "avr_cabac_resolve_workspace_bytes": (c_size_t, [c_size_t, c_size_t, c_void_p]),
     "avr_cabac_resolve_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                          c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),

@@ -387,8 +387,8 @@ static int submit_impl(avr_batch *b, bool use_hint) {
     const size_t n_tiles = tile_off.size() - 1;
     // One lane per slice needs tens of thousands of slices to fill the chip; a batch of few, long
     // slices (a clip with one slice per frame) goes through the intra-slice parallel kernels.
-    bool chunked = cabac && n <= 32768 && b->total_bins / n >= 8192;
-    if (const char *force = getenv("AVR_K1_PATH")) chunked = cabac && strcmp(force, "chunked") == 0;
+    bool chunked = n <= 32768 && b->total_bins / n >= 8192;
+    if (const char *force = getenv("AVR_K1_PATH")) chunked = strcmp(force, "chunked") == 0;
     b->last_path = chunked;
 
     int rc;
@@ -424,7 +424,24 @@ static int submit_impl(avr_batch *b, bool use_hint) {
     AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
     // Both K1 paths renumber the batch onto the contexts it uses themselves (the intra-slice parallel kernels inside
     // their census pass, the one-lane-per-slice kernel through launch_cabac_encode): records and states go in as they are.
-    if (chunked) {
+    if (chunked && !cabac) {
+        // K2 for few, long slices: the range recurrence per slice, everything else per chunk (avr_k2p.hip)
+        std::vector<uint32_t> chunk_base(n + 1, 0), chunk_slice;
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t nc = uint32_t(std::max<uint64_t>(1, (uint64_t(b->n_bins[i]) + AVR_CHUNK_BINS - 1) / AVR_CHUNK_BINS));
+            chunk_base[i + 1] = chunk_base[i] + nc;
+            chunk_slice.insert(chunk_slice.end(), nc, uint32_t(i));
+        }
+        const size_t ws = avr::k2p_workspace_bytes(n, chunk_base.back(), total_out);
+        if ((rc = b->d_chunk_base.reserve(n + 1)) || (rc = b->d_chunk_slice.reserve(chunk_slice.size())) || (rc = b->d_workspace.reserve(ws + 256)))
+            return rc;
+        AVR_STAGE(b->d_chunk_base.p, chunk_base.data(), n + 1);
+        AVR_STAGE(b->d_chunk_slice.p, chunk_slice.data(), chunk_slice.size());
+        AVR_HIP(hipEventRecord(b->ev[2], s));
+        uint8_t *wsp = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(b->d_workspace.p) + 255) & ~uintptr_t(255));
+        AVR_HIP(avr::launch_k2p(s, b->d_recs.p, b->d_rec_off.p, b->d_n_bins.p, n32, b->d_chunk_base.p, b->d_chunk_slice.p,
+                                chunk_base.back(), total_out, wsp, b->d_out.p, b->d_out_off.p, b->d_out_len.p, b->d_status.p));
+    } else if (chunked) {
         std::vector<uint64_t> res_off(n + 1, 0), dig_off(n + 1, 0);
         std::vector<uint32_t> chunk_base(n + 1, 0), blk_base(n + 1, 0), chunk_slice, blk_slice;
         for (size_t i = 0; i < n; i++) {
@@ -783,6 +800,25 @@ int avr_cabac_encode_chunked_device(int device, void *stream, const uint16_t *re
     if (int rc = select_device(device)) return rc;
     AVR_HIP(avr::launch_k1p(static_cast<hipStream_t>(stream), recs, rec_off, n_bins, uint32_t(n_slices), init_states,
                             uint32_t(n_states), plan, workspace, out, out_off, out_len, status, final_states));
+    return AVR_OK;
+}
+
+size_t avr_range_chunked_workspace_bytes(size_t n_slices, const avr_chunk_plan *plan, uint64_t out_total) {
+    if (!plan) return 0;
+    return avr::k2p_workspace_bytes(n_slices, plan->total_chunks, out_total);
+}
+
+int avr_range_encode_chunked_device(int device, void *stream, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                                    size_t n_slices, const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes,
+                                    uint8_t *out, const uint64_t *out_off, uint64_t out_total, uint32_t *out_len, int32_t *status) {
+    if (int rc = check_common(rec_off, n_bins, out_off, n_slices)) return rc;
+    if (!plan || (n_slices && (!plan->chunk_base || !plan->chunk_slice || !workspace || !status || !out || !out_len)))
+        return fail(AVR_ERR_INVALID, "null plan / workspace / output pointer");
+    if (workspace_bytes < avr::k2p_workspace_bytes(n_slices, plan->total_chunks, out_total))
+        return fail(AVR_ERR_CAPACITY, "workspace of %zu bytes is smaller than avr_range_chunked_workspace_bytes()", workspace_bytes);
+    if (int rc = select_device(device)) return rc;
+    AVR_HIP(avr::launch_k2p(static_cast<hipStream_t>(stream), recs, rec_off, n_bins, uint32_t(n_slices), plan->chunk_base,
+                            plan->chunk_slice, plan->total_chunks, out_total, workspace, out, out_off, out_len, status));
     return AVR_OK;
 }
 

@@ -83,6 +83,11 @@ hipError_t launch_k1p_code(hipStream_t s, const uint8_t *codes, const uint32_t *
 hipError_t launch_cabac_encode_codes(hipStream_t s, const uint8_t *codes, const uint64_t *res_off, const uint32_t *n_bins,
                                      const uint32_t *order, uint32_t n_slices, uint8_t *out, const uint64_t *out_off,
                                      uint32_t *out_len, int32_t *status, int32_t want_status = AVR_SLICE_OK);
+// K2 for few, long slices (avr_k2p.hip): range recurrence per slice, coding per chunk into byte sums, carries + finish
+size_t k2p_workspace_bytes(size_t n_slices, uint32_t total_chunks, uint64_t out_total);
+hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins, uint32_t n_slices,
+                      const uint32_t *chunk_base, const uint32_t *chunk_slice, uint32_t total_chunks, uint64_t out_total,
+                      void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status);
 hipError_t launch_synth_slices(hipStream_t s, int workload, uint32_t scale, uint64_t seed, uint64_t first_slice,
                                int kind, uint32_t n_slices, const uint64_t *rec_off, uint16_t *recs,
                                uint8_t *init_states, uint32_t n_states);

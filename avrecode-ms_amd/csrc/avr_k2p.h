@@ -1,0 +1,93 @@
+// K2p: the recoded range coder (arithmetic_code<uint64_t, uint8_t>, recode.cpp:322-323, with
+// p(1) = (range / total) * pos, recode.cpp:823-827) for batches of few, long slices, in three passes.
+//
+// What can and what cannot be done in parallel.  The coder's state is (low, range).  `range` obeys an exact 63-bit
+// integer recurrence on its own previous value, range <- (range / total) * pos or range minus that
+// (arithmetic_code.h:107-114), with a shift by 8 whenever it drops below 2^51 (:115-122): unlike CABAC's 9-bit range
+// with its four-quarter table there is no small state to speculate on, so the recurrence is walked bin by bin, one
+// lane per slice (pass 1) -- the wall of this path.  `low`, however, is a sum: every bin adds a term that depends on
+// the range alone (:110), at a bit position given by the number of shifts so far.  With the range and the shift
+// count noted at every chunk boundary,
+//   pass 1  range recurrence per slice; per chunk of kChunk bins: range and bytes emitted at its start
+//   pass 2  one lane per chunk: the real coder from (low = 0, the noted range), its bytes ADDED into 32-bit sums per
+//           byte position of the slice (a byte it emits with the carry bit set simply adds 256: one into the byte
+//           before), and what is left of its low at the chunk's end added over the eight positions that follow
+//   pass 3  per slice: carries over the sums from the last byte, which leaves the reference's bytes and, in the eight
+//           positions past the last emitted byte, the reference's final low; finish() (:128-144) as it is
+// give the reference's bytes.  Everything here is `__host__ __device__`: tests/k2p_emul.cpp runs the same functions on
+// the CPU against the oracle.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define AVR_K2P_HD __host__ __device__ inline
+#else
+#define AVR_K2P_HD inline
+#endif
+
+namespace avr {
+namespace k2p {
+
+constexpr uint32_t kChunk = 1024;                      // bins per chunk
+constexpr uint64_t kOne = uint64_t(1) << 63;           // fixed_one (arithmetic_code.h:54-55)
+constexpr uint64_t kMinRange = uint64_t(1) << 51;      // arithmetic_code.h:61-62
+constexpr uint32_t kTail = 8;                          // byte positions a chunk's left-over low is spread over
+
+// One bin (arithmetic_code.h:106-126 with recode.cpp:823-827).  `div(range, total)` = range / total; `emit(byte9)` takes
+// each byte shifted out, carry bit included (0 .. 511).  WITH_LOW = false: the range recurrence alone (pass 1).
+// Returns false when the bin has probability zero (arithmetic_code.h:116-118): the slice is in error.
+template <bool WITH_LOW, class Div, class Emit>
+AVR_K2P_HD bool bin(uint64_t &low, uint64_t &range, uint32_t rec, Div &&div, Emit &&emit) {
+    const uint32_t b = rec & 1u, pos = (rec >> 1) & 0x7fu, total = pos + ((rec >> 8) & 0x7fu);   // recode.cpp:825
+    if (total == 0) return true;                       // padding record
+    const uint64_t r1 = div(range, total) * pos;       // recode.cpp:826
+    const uint64_t r0 = range - r1;                    // arithmetic_code.h:108
+    if (WITH_LOW) low += b ? r0 : 0;
+    range = b ? r1 : r0;
+    if (range < kMinRange) {                           // :115
+        if (range == 0) return false;                  // :116-118
+        do {                                           // :120-122, renormalize_and_emit_digit<uint8_t> (:147-180)
+            emit(WITH_LOW ? uint32_t(low >> 55) : 0u); // bit 8 of the byte: the carry (low >= fixed_one)
+            if (WITH_LOW) low = (low & ((uint64_t(1) << 55) - 1)) << 8;
+            range <<= 8;
+        } while (range < (kMinRange << 4));
+    }
+    return true;
+}
+
+// What is left of a chunk's low, as kTail bytes behind the ones it emitted (byte j: bits 62 - 8j .. 55 - 8j of low, the
+// first with the carry bit on top, the last with the seven bits that remain, shifted up by one).
+template <class Emit>
+AVR_K2P_HD void leftover(uint64_t low, Emit &&emit) {
+    emit(uint32_t(low >> 55));
+    for (uint32_t j = 1; j < 7; j++) emit(uint32_t(low >> (55 - 8 * j)) & 0xffu);
+    emit(uint32_t(low & 0x7fu) << 1);
+}
+
+// The reference's final low from the kTail normalised bytes past the last emitted one.
+AVR_K2P_HD uint64_t low_from_tail(const uint8_t t[kTail]) {
+    uint64_t low = 0;
+    for (uint32_t j = 0; j < 7; j++) low |= uint64_t(t[j]) << (55 - 8 * j);
+    return low | (t[7] >> 1);
+}
+
+// finish() of arithmetic_code<uint64_t, uint8_t>::encoder (arithmetic_code.h:128-144) on the exact final (low, range):
+// the bytes it appends (at most 9) and the carry it sends into the bytes before them.
+AVR_K2P_HD uint32_t finish(uint64_t low, uint64_t range, uint8_t tail[9], uint32_t *carry) {
+    for (uint64_t stop = kOne >> 1; stop > 0; stop >>= 1) {          // :131-137
+        const uint64_t x = (low | stop) & ~(stop - 1);
+        if (stop < range && low <= x && x < uint64_t(low + range)) { low = x; break; }
+    }
+    uint32_t n = 0, cy = 0;
+    while (low != 0 && n < 9) {                                      // :139-142
+        if (low >= kOne) { cy = 1; low -= kOne; }
+        const uint32_t d = uint32_t(low >> 55);
+        tail[n++] = uint8_t(d);
+        low = (low - (uint64_t(d) << 55)) << 8;
+    }
+    *carry = cy;
+    return n;
+}
+
+}  // namespace k2p
+}  // namespace avr

@@ -1,0 +1,216 @@
+// K2p kernels: the recoded range coder (compress direction) for batches of few, long slices.  The decomposition and the
+// per-lane functions are in avr_k2p.h; this file maps them to lanes:
+//
+//   k_k2p_ranges   pass 1   lane per slice       the range recurrence; range and bytes emitted at every chunk start
+//   k_k2p_code     pass 2   lane per chunk       the coder from (low = 0, noted range); bytes added into 32-bit sums
+//   k_k2p_finish   pass 3   workgroup per slice  carries from the last byte, finish(), bytes out
+//
+// Input is the slice-major record layout (a slice's records consecutive, padded with no-op records to a multiple of 8).
+// Pass 1 is the wall: one lane per slice, one dependent chain of a 63-bit division, a multiply and a compare per bin
+// (DESIGN.md section 4); passes 2 and 3 together take a few percent of it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "avr_div.h"
+#include "avr_internal.h"
+#include "avr_k2p.h"
+
+namespace avr {
+
+using namespace k2p;
+
+namespace {
+
+struct U4 { uint32_t x, y, z, w; };
+
+struct K2Plan {
+    const uint16_t *recs;
+    const uint64_t *rec_off;
+    const uint32_t *n_bins;
+    const uint32_t *chunk_base, *chunk_slice;
+    const uint64_t *out_off;        // the slice's bytes in `out`, and its sums in S, start here (capacity n_bins + 16 at least)
+};
+
+// fl(1 / d) for avr_div.h, per workgroup
+__device__ __forceinline__ void fill_inv(double *inv) {
+    for (uint32_t d = threadIdx.x; d < 256; d += blockDim.x) inv[d] = d ? 1.0 / double(d) : 0.0;
+}
+
+// Eight records: operands first (they depend on the records alone: no LDS latency on the range chain), then the bins.
+template <bool WITH_LOW, class Emit>
+__device__ __forceinline__ bool eight(const U4 &v, const double *inv, uint64_t &low, uint64_t &range, Emit &&emit) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t rec[8];
+    double iv[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        rec[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+        iv[k] = inv[((rec[k] >> 1) & 0x7fu) + ((rec[k] >> 8) & 0x7fu)];
+    }
+    bool ok = true;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        const double i1 = iv[k];
+        // (after a bin of probability zero the rest is skipped: measured faster than walking on, 105 against 118 ms on config 2)
+        ok = ok && bin<WITH_LOW>(low, range, rec[k], [i1](uint64_t r, uint32_t t) { return div_u64_small_f64(r, double(t), i1); }, emit);
+    }
+    return ok;
+}
+
+// Pass 1.  One lane per slice; ck_range / ck_pos: the range and the number of bytes emitted when chunk c of the slice
+// begins; fin_range / fin_pos: at the slice's end.  A zero-probability bin (arithmetic_code.h:116-118) ends the slice
+// with AVR_SLICE_ZERO_PROB.
+__global__ __launch_bounds__(64) void k_k2p_ranges(K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
+                                                  uint64_t *fin_range, uint32_t *fin_pos, int32_t *status) {
+    __shared__ double inv[256];
+    fill_inv(inv);
+    __syncthreads();
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_slices || status[s] != AVR_SLICE_OK) return;
+    const uint32_t n = p.n_bins[s], c0 = p.chunk_base[s];
+    const U4 *r = reinterpret_cast<const U4 *>(p.recs + p.rec_off[s]);
+    const uint32_t n_groups = (n + 7) >> 3, last = n_groups ? n_groups - 1 : 0;
+    uint64_t range = kOne, low = 0;                              // arithmetic_code.h:96-97
+    uint32_t pos = 0;
+    bool ok = true;                                              // a bin of probability zero puts the slice in error and ends the walk
+    auto count = [&](uint32_t) { pos++; };
+    // A cache line of records (four groups) per trip, two lines in flight ahead of the chain; every load is unconditional
+    // (the index clamped to the slice's last group: what a clamped load returns is never coded).
+    auto line = [&](uint32_t g, U4 v[4]) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) v[k] = r[g + k < last ? g + k : last];
+    };
+    U4 cur[4], nx1[4];
+    if (n_groups) { line(0, cur); line(4, nx1); }
+    for (uint32_t g = 0; g < n_groups && ok; g += 4) {
+        U4 nx2[4];
+        line(g + 8, nx2);
+        if ((g & (kChunk / 8 - 1)) == 0) { ck_range[c0 + (g >> 7)] = range; ck_pos[c0 + (g >> 7)] = pos; }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            if (g + k < n_groups && ok) ok = eight<false>(cur[k], inv, low, range, count);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { cur[k] = nx1[k]; nx1[k] = nx2[k]; }
+    }
+    if (n_groups == 0) { ck_range[c0] = range; ck_pos[c0] = 0; }  // an empty slice still has its one chunk
+    fin_range[s] = range;
+    fin_pos[s] = pos;
+    if (!ok) status[s] = AVR_SLICE_ZERO_PROB;
+}
+
+// Pass 2.  One lane per chunk: the coder itself over the chunk's bins, from low = 0 and the range noted by pass 1; every
+// byte it shifts out (carry bit included) is added to the sum of its position in the slice, and what is left of low at
+// the end to the kTail positions behind.  Lanes of neighbouring chunks add into the same positions where they meet.
+__global__ __launch_bounds__(256) void k_k2p_code(K2Plan p, uint32_t total_chunks, const uint64_t *ck_range, const uint32_t *ck_pos,
+                                                 const int32_t *status, uint32_t *S) {
+    __shared__ double inv[256];
+    fill_inv(inv);
+    __syncthreads();
+    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
+    if (gc >= total_chunks) return;
+    const uint32_t s = p.chunk_slice[gc];
+    if (status[s] != AVR_SLICE_OK) return;
+    const uint32_t c = gc - p.chunk_base[s], n = p.n_bins[s], i0 = c * kChunk;
+    const uint32_t i1 = i0 + kChunk < n ? i0 + kChunk : n;
+    const uint16_t *r = p.recs + p.rec_off[s];
+    uint32_t *at = S + p.out_off[s] + ck_pos[gc];
+    uint32_t *const shared_end = at + kTail;                     // up to here the chunks before this one may have left bytes of their low
+    uint64_t low = 0, range = ck_range[gc];
+    auto add = [&](uint32_t v) {
+        if (at < shared_end) atomicAdd(at, v); else *at = v;     // (behind it the position is this chunk's alone, until its own left-over)
+        at++;
+    };
+    auto add_shared = [&](uint32_t v) { atomicAdd(at, v); at++; };
+    // a cache line of records per trip, the next one in flight (a slice's records are padded to whole groups of 8)
+    uint32_t i = i0;
+    U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+    if (i + 32 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i); v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
+    for (; i + 32 <= i1; i += 32) {
+        U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
+        if (i + 64 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i + 32); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+        eight<true>(v0, inv, low, range, add); eight<true>(v1, inv, low, range, add);
+        eight<true>(v2, inv, low, range, add); eight<true>(v3, inv, low, range, add);
+        v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+    }
+    for (; i < i1; i += 8) eight<true>(*reinterpret_cast<const U4 *>(r + i), inv, low, range, add);
+    leftover(low, add_shared);
+}
+
+// Pass 3.  One 64-lane workgroup per slice.  Positions [0, P + kTail) of the slice's sums, P = bytes emitted: carries from
+// the last position (tiles of kFinTile through LDS: loads and byte stores by all lanes, the carry chain by lane 0);
+// the kTail positions past P then hold the reference's final low, to which finish() (arithmetic_code.h:128-144) is
+// applied as it stands.
+constexpr uint32_t kFinTile = 4096;
+__global__ __launch_bounds__(64) void k_k2p_finish(K2Plan p, const uint64_t *fin_range, const uint32_t *fin_pos, const uint32_t *S,
+                                                  uint8_t *out, uint32_t *out_len, int32_t *status) {
+    __shared__ uint32_t dig[kFinTile];
+    __shared__ uint8_t tail_bytes[kTail];
+    __shared__ uint32_t sh_carry;
+    const uint32_t s = blockIdx.x, t = threadIdx.x;
+    if (status[s] != AVR_SLICE_OK) { if (t == 0) out_len[s] = 0; return; }
+    const uint32_t P = fin_pos[s];
+    const uint32_t *Ss = S + p.out_off[s];
+    uint8_t *o = out + p.out_off[s];
+    const uint32_t cap = uint32_t(p.out_off[s + 1] - p.out_off[s]);
+    if (t == 0) sh_carry = 0;
+    __syncthreads();
+    for (uint32_t hi = P + kTail; hi > 0;) {
+        const uint32_t lo = hi > kFinTile ? hi - kFinTile : 0, cnt = hi - lo;
+        for (uint32_t i = t; i < cnt; i += 64) dig[i] = Ss[lo + i];
+        __syncthreads();
+        if (t == 0) {
+            uint32_t c = sh_carry;
+            for (uint32_t i = cnt; i-- > 0;) { const uint32_t v = dig[i] + c; dig[i] = v & 0xffu; c = v >> 8; }
+            sh_carry = c;
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < cnt; i += 64) {
+            const uint32_t at = lo + i;
+            if (at >= P) tail_bytes[at - P] = uint8_t(dig[i]);
+            else if (at < cap) o[at] = uint8_t(dig[i]);
+        }
+        hi = lo;
+        __syncthreads();
+    }
+    if (t == 0) {
+        uint8_t tail[9];
+        uint32_t cy;
+        const uint32_t n_tail = finish(low_from_tail(tail_bytes), fin_range[s], tail, &cy);
+        for (uint32_t k = 0; k < n_tail; k++)
+            if (P + k < cap) o[P + k] = tail[k];
+        for (uint32_t i = P < cap ? P : cap; cy && i-- > 0;) { const uint32_t b = uint32_t(o[i]) + 1u; o[i] = uint8_t(b); cy = b >> 8; }
+        out_len[s] = P + n_tail;
+        if (P + n_tail > cap) status[s] = AVR_SLICE_OVERFLOW;
+    }
+}
+
+inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
+
+}  // namespace
+
+// workspace: ck_range, ck_pos per chunk; fin_range, fin_pos per slice; 32-bit sums per output byte position
+size_t k2p_workspace_bytes(size_t n_slices, uint32_t total_chunks, uint64_t out_total) {
+    return size_t(up256(uint64_t(total_chunks) * 8) + up256(uint64_t(total_chunks) * 4) + up256(n_slices * 8) + up256(n_slices * 4) +
+                  up256(out_total * 4 + 64));
+}
+
+hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins, uint32_t n_slices,
+                      const uint32_t *chunk_base, const uint32_t *chunk_slice, uint32_t total_chunks, uint64_t out_total,
+                      void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
+    if (n_slices == 0) return hipSuccess;
+    uint8_t *w = static_cast<uint8_t *>(workspace);
+    uint64_t *ck_range = reinterpret_cast<uint64_t *>(w);    w += up256(uint64_t(total_chunks) * 8);
+    uint32_t *ck_pos = reinterpret_cast<uint32_t *>(w);      w += up256(uint64_t(total_chunks) * 4);
+    uint64_t *fin_range = reinterpret_cast<uint64_t *>(w);   w += up256(uint64_t(n_slices) * 8);
+    uint32_t *fin_pos = reinterpret_cast<uint32_t *>(w);     w += up256(uint64_t(n_slices) * 4);
+    uint32_t *S = reinterpret_cast<uint32_t *>(w);
+    const K2Plan p{recs, rec_off, n_bins, chunk_base, chunk_slice, out_off};
+    hipError_t e = hipMemsetAsync(S, 0, out_total * 4 + 64, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_k2p_ranges, dim3((n_slices + 63) / 64), dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status);
+    hipLaunchKernelGGL(k_k2p_code, dim3((total_chunks + 255) / 256), dim3(256), 0, s, p, total_chunks, ck_range, ck_pos, status, S);
+    hipLaunchKernelGGL(k_k2p_finish, dim3(n_slices), dim3(64), 0, s, p, fin_range, fin_pos, S, out, out_len, status);
+    return hipGetLastError();
+}
+
+}  // namespace avr

@@ -232,17 +232,31 @@ class DeviceWorkload:
             plan = ChunkPlan(t["res_off"].data_ptr(), t["chunk_base"].data_ptr(), t["chunk_slice"].data_ptr(),
                              t["blk_base"].data_ptr(), t["blk_slice"].data_ptr(), t["dig_off"].data_ptr(),
                              int(res_off[-1]), int(dig_off[-1]), int(chunk_base[-1]), int(blk_base[-1]))
-            ws_bytes = lib().avr_cabac_chunked_workspace_bytes(self.n_slices, self.n_states, ctypes.byref(plan))
-            self._plan = dict(tensors=t, plan=plan, ws_bytes=ws_bytes,
-                              ws=torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev))
+            self._plan = dict(tensors=t, plan=plan)
+            if self.kind == KIND_CABAC:                     # (K2 sizes its own workspace, see encode_chunked)
+                ws_bytes = lib().avr_cabac_chunked_workspace_bytes(self.n_slices, self.n_states, ctypes.byref(plan))
+                self._plan.update(ws_bytes=ws_bytes, ws=torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev))
         return self._plan
 
     def encode_chunked(self):
-        """K1 through the intra-slice parallel kernels (same bytes as encode())."""
+        """K1 / K2 through the intra-slice parallel kernels (same bytes as encode())."""
         import torch
-        assert self.kind == KIND_CABAC
         recs, rec_off = self._slice_major()
         p = self._chunk_plan()
+        if self.kind != KIND_CABAC:
+            L = lib()
+            out_total = int(self.out_off[-1].item()) if "out_total" not in p else p["out_total"]
+            p["out_total"] = out_total
+            if "ws_k2" not in p:
+                n = L.avr_range_chunked_workspace_bytes(self.n_slices, ctypes.byref(p["plan"]), out_total)
+                p["ws_k2"] = torch.empty(n + 256, dtype=torch.uint8, device=self.n_bins.device)
+                p["ws_k2_bytes"] = n
+            ws_ptr = (p["ws_k2"].data_ptr() + 255) // 256 * 256
+            _check(L.avr_range_encode_chunked_device(
+                self.device_index, _stream_ptr(torch), recs.data_ptr(), rec_off.data_ptr(), self.n_bins.data_ptr(), self.n_slices,
+                ctypes.byref(p["plan"]), ws_ptr, p["ws_k2_bytes"], self.out.data_ptr(), self.out_off.data_ptr(), out_total,
+                self.out_len.data_ptr(), self.status.data_ptr()))
+            return
         ws_ptr = (p["ws"].data_ptr() + 255) // 256 * 256
         _check(lib().avr_cabac_encode_chunked_device(
             self.device_index, _stream_ptr(torch), recs.data_ptr(), rec_off.data_ptr(), self.n_bins.data_ptr(),

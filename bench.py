@@ -205,9 +205,7 @@ def main():
 
     path = args.path
     if path == "auto":        # one lane per slice needs >= ~64 slices per SIMD-wave-slot to fill 256 CUs
-        path = "chunked" if (kind == avr.KIND_CABAC and n_slices <= 32768 and w.total_bins // max(n_slices, 1) >= 8192) else "serial"
-    if kind != avr.KIND_CABAC:
-        path = "serial"
+        path = "chunked" if (n_slices <= 32768 and w.total_bins // max(n_slices, 1) >= 8192) else "serial"
     # The step contains everything a batch needs: both K1 paths renumber the batch onto the contexts it uses inside the
     # call (the intra-slice parallel kernels in their census pass; the one-lane-per-slice kernel through a census of its
     # own and a look-up as records are loaded), nothing happens before the first step.
@@ -277,7 +275,9 @@ def main():
                          "kernel": ("K1p: k_k1p_{census,densemap,tn,local,ctxchain,replay,b2,zero,c,d} + the idle serial fallback (one step = "
                                     "all of them; largest: k_k1p_replay)" if path == "chunked" else
                                     "k_k1_census (1-in-16 sample) + k_k1p_densemap + k_cabac_encode<tiled> + its hand-back launch (one step = all of them)")
-                         if kind == avr.KIND_CABAC else "k_range_encode<tiled>",
+                         if kind == avr.KIND_CABAC else
+                         ("K2p: k_k2p_ranges (the range recurrence, one lane per slice: the wall) + k_k2p_code + k_k2p_finish"
+                          if path == "chunked" else "k_range_encode<tiled>"),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
                          "bins_per_s": w.total_bins / (kernel_ms * 1e-3)},
             "slice_status_errors": status_bad,

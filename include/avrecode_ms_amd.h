@@ -254,6 +254,20 @@ int avr_cabac_encode_chunked_device(int device, void *stream,
                                     uint8_t *out, const uint64_t *out_off,
                                     uint32_t *out_len, int32_t *status, uint8_t *final_states);
 
+/* K2, intra-slice parallel form ("K2p", avrecode-ms_amd/csrc/avr_k2p.h): the same bytes as avr_range_encode_slices_device for
+ * batches of few, long slices.  The range recurrence of arithmetic_code<uint64_t, uint8_t> (recode.cpp:322-323, 823-827) is
+ * walked by one lane per slice -- it is exact 63-bit arithmetic on its own previous value and does not decompose --
+ * while low, the output bytes, the carries and finish() (arithmetic_code.h:128-144) are done per chunk of AVR_CHUNK_BINS
+ * bins and per slice.  Of the plan only chunk_base, chunk_slice and total_chunks are used; out_total = out_off[n_slices];
+ * out_off as for the other entry points (capacity n_bins + 16 per slice at least).  Input is the slice-major layout. */
+size_t avr_range_chunked_workspace_bytes(size_t n_slices, const avr_chunk_plan *plan, uint64_t out_total);
+int avr_range_encode_chunked_device(int device, void *stream,
+                                    const uint16_t *recs, const uint64_t *rec_off,
+                                    const uint32_t *n_bins, size_t n_slices,
+                                    const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes,
+                                    uint8_t *out, const uint64_t *out_off, uint64_t out_total,
+                                    uint32_t *out_len, int32_t *status);
+
 /* The two stages of K1p on their own.
  *
  * Stage 1, avr_cabac_resolve_device: context-state resolution (phase A).  Writes one RESOLVED CODE

@@ -363,3 +363,43 @@ def test_chunked_census_sample_second_pass_and_validation(avr, oracle, stride, m
         want = oracle.cabac_encode(r, s)
         assert status[i] == 0 and got[i] == want[0] and fs[i].tobytes() == want[1], f"slice {i} n={len(r)}"
     assert list(status[good:]) == [avr.SLICE_BAD_RECORD] * 5
+
+
+# ------------------------------------------------------------------ K2p: the recoded range coder in three passes
+
+def test_range_chunked_random_and_extremes(avr, oracle):
+    """avr_range_encode_chunked_device against the oracle: ragged lengths around the chunk size, adaptive and fixed
+    estimators, certain bins (no output for thousands of bins), the most lopsided estimators, empty slices, and a
+    zero-probability bin in the middle of a slice (status, like arithmetic_code.h:116-118)."""
+    rng = np.random.default_rng(17)
+    def rec(b, pos, neg):
+        return b | (pos << 1) | (neg << 8)
+    slices = [oracle_lib.random_range_stream(rng, n, adaptive=bool(i % 3))
+              for i, n in enumerate([0, 1, 7, 8, 9, 1023, 1024, 1025, 2047, 2048, 4097, 30000, 12345, 50000, 3, 20000])]
+    slices += [np.array([rec(1, 0x5f, 1)] * 9000, np.uint16), np.array([rec(0, 0x5f, 1)] * 5000, np.uint16),
+               np.array([rec(1, 9, 0)] * 6000 + [rec(0, 1, 1)] * 40, np.uint16), np.array([rec(i & 1, 1, 1) for i in range(7000)], np.uint16)]
+    zero = oracle_lib.random_range_stream(rng, 5000)
+    zero[2500] = np.uint16(1 | (0 << 1) | (9 << 8))
+    slices.append(zero)
+    w = avr.DeviceWorkload.from_host(1, slices, None, 0)
+    w.encode_chunked()
+    got, status = w.results()
+    for i, r in enumerate(slices[:-1]):
+        want, st = oracle.range_encode(r)
+        assert st == 0 and status[i] == 0 and got[i] == want, f"slice {i} n={len(r)}"
+    assert status[-1] == avr.SLICE_ZERO_PROB and oracle.range_encode(zero)[1] == 1
+
+
+def test_range_chunked_config2_cut_equals_the_serial_kernel(avr, oracle):
+    """A 24-slice cut of BASELINE.json's configs[1] in the compress direction: the three-pass path and the one-lane-per-slice
+    kernel give the same bytes, and sampled slices equal the oracle's."""
+    w = avr.DeviceWorkload.synth(2, 24, avr.KIND_RANGE, 0, 1000)
+    w.encode()
+    serial, st0 = w.results()
+    w.out.zero_()
+    w.encode_chunked()
+    chunked, st1 = w.results()
+    assert not any(st0) and not any(st1) and chunked == serial
+    for s in (0, 11, 23):
+        cfg, nbh, off, recs, _ = host_synth(avr, 2, 1, avr.KIND_RANGE, 1000, first=s)
+        assert chunked[s] == oracle.range_encode(recs[:int(nbh[0])])[0]
