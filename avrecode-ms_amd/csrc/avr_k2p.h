@@ -33,13 +33,14 @@ constexpr uint64_t kOne = uint64_t(1) << 63;           // fixed_one (arithmetic_
 constexpr uint64_t kMinRange = uint64_t(1) << 51;      // arithmetic_code.h:61-62
 constexpr uint32_t kTail = 8;                          // byte positions a chunk's left-over low is spread over
 
-// One bin (arithmetic_code.h:106-126 with recode.cpp:823-827).  `div(range, total)` = range / total; `emit(byte9)` takes
-// each byte shifted out, carry bit included (0 .. 511).  WITH_LOW = false: the range recurrence alone (pass 1).
+// One bin (arithmetic_code.h:106-126 with recode.cpp:823-827).  `div(range, total)` = range / total, and 0 for total 0 (a
+// padding record: it then changes nothing, without a branch of its own on the chain); `emit(byte9)` takes each byte
+// shifted out, carry bit included (0 .. 511).  WITH_LOW = false: the range recurrence alone (pass 1).
 // Returns false when the bin has probability zero (arithmetic_code.h:116-118): the slice is in error.
 template <bool WITH_LOW, class Div, class Emit>
 AVR_K2P_HD bool bin(uint64_t &low, uint64_t &range, uint32_t rec, Div &&div, Emit &&emit) {
-    const uint32_t b = rec & 1u, pos = (rec >> 1) & 0x7fu, total = pos + ((rec >> 8) & 0x7fu);   // recode.cpp:825
-    if (total == 0) return true;                       // padding record
+    const uint32_t pos = (rec >> 1) & 0x7fu, total = pos + ((rec >> 8) & 0x7fu);                 // recode.cpp:825
+    const uint32_t b = total ? rec & 1u : 0u;          // padding record (total 0): quotient 0, r1 = 0, range and low stay
     const uint64_t r1 = div(range, total) * pos;       // recode.cpp:826
     const uint64_t r0 = range - r1;                    // arithmetic_code.h:108
     if (WITH_LOW) low += b ? r0 : 0;

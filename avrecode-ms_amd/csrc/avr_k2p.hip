@@ -98,6 +98,22 @@ __global__ __launch_bounds__(64) void k_k2p_ranges(K2Plan p, uint32_t n_slices, 
     if (!ok) status[s] = AVR_SLICE_ZERO_PROB;
 }
 
+// Between the passes: the positions that will be ADDED into are zeroed -- the first kTail of every chunk (where earlier chunks
+// may leave bytes of their low) and the kTail behind the slice's last byte; every other position gets one plain store.
+__global__ __launch_bounds__(256) void k_k2p_zero(K2Plan p, uint32_t total_chunks, const uint32_t *ck_pos, const uint32_t *fin_pos,
+                                                 const int32_t *status, uint32_t *S) {
+    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
+    if (gc >= total_chunks) return;
+    const uint32_t s = p.chunk_slice[gc];
+    if (status[s] != AVR_SLICE_OK) return;
+    uint32_t *at = S + p.out_off[s] + ck_pos[gc];
+    for (uint32_t j = 0; j < kTail; j++) at[j] = 0;
+    if (gc + 1 == p.chunk_base[s + 1]) {                         // the slice's last chunk: also behind its last byte
+        uint32_t *end = S + p.out_off[s] + fin_pos[s];
+        for (uint32_t j = 0; j < kTail; j++) end[j] = 0;
+    }
+}
+
 // Pass 2.  One lane per chunk: the coder itself over the chunk's bins, from low = 0 and the range noted by pass 1; every
 // byte it shifts out (carry bit included) is added to the sum of its position in the slice, and what is left of low at
 // the end to the kTail positions behind.  Lanes of neighbouring chunks add into the same positions where they meet.
@@ -140,34 +156,50 @@ __global__ __launch_bounds__(256) void k_k2p_code(K2Plan p, uint32_t total_chunk
 // the last position (tiles of kFinTile through LDS: loads and byte stores by all lanes, the carry chain by lane 0);
 // the kTail positions past P then hold the reference's final low, to which finish() (arithmetic_code.h:128-144) is
 // applied as it stands.
-constexpr uint32_t kFinTile = 4096;
+constexpr uint32_t kFinTile = 4096, kFinSeg = kFinTile / 64, kFinRow = kFinSeg + 1;   // a lane's segment, padded by one word: no bank conflicts
 __global__ __launch_bounds__(64) void k_k2p_finish(K2Plan p, const uint64_t *fin_range, const uint32_t *fin_pos, const uint32_t *S,
                                                   uint8_t *out, uint32_t *out_len, int32_t *status) {
-    __shared__ uint32_t dig[kFinTile];
+    __shared__ uint32_t dig[64 * kFinRow];
+    __shared__ uint32_t cout[65];
     __shared__ uint8_t tail_bytes[kTail];
-    __shared__ uint32_t sh_carry;
     const uint32_t s = blockIdx.x, t = threadIdx.x;
     if (status[s] != AVR_SLICE_OK) { if (t == 0) out_len[s] = 0; return; }
     const uint32_t P = fin_pos[s];
     const uint32_t *Ss = S + p.out_off[s];
     uint8_t *o = out + p.out_off[s];
     const uint32_t cap = uint32_t(p.out_off[s + 1] - p.out_off[s]);
-    if (t == 0) sh_carry = 0;
-    __syncthreads();
+    uint32_t tile_carry = 0;                                     // into the last position of the tile being done (same in every lane)
+    // Tiles from the last position.  A tile is aligned to its END: entry e of the tile (position lo + e - pad) sits in segment
+    // e / kFinSeg, and segment 63 ends at the tile's last position; a short first tile leaves its low segments empty (zeros).
     for (uint32_t hi = P + kTail; hi > 0;) {
-        const uint32_t lo = hi > kFinTile ? hi - kFinTile : 0, cnt = hi - lo;
-        for (uint32_t i = t; i < cnt; i += 64) dig[i] = Ss[lo + i];
+        const uint32_t lo = hi > kFinTile ? hi - kFinTile : 0, cnt = hi - lo, pad = kFinTile - cnt;
+        for (uint32_t e = t; e < kFinTile; e += 64) dig[(e / kFinSeg) * kFinRow + e % kFinSeg] = e >= pad ? Ss[lo + e - pad] : 0u;
         __syncthreads();
-        if (t == 0) {
-            uint32_t c = sh_carry;
-            for (uint32_t i = cnt; i-- > 0;) { const uint32_t v = dig[i] + c; dig[i] = v & 0xffu; c = v >> 8; }
-            sh_carry = c;
+        // every lane its own segment from the segment's last entry, then the carries between segments until none is left:
+        // integer addition in another order.  After the first sweep every entry is a byte, so a carry that arrives only
+        // travels through 0xff entries: the loop ends after a round or two.
+        uint32_t *seg = dig + t * kFinRow;
+        uint32_t c = t == 63 ? tile_carry : 0u;
+        for (uint32_t i = kFinSeg; i-- > 0;) { const uint32_t v = seg[i] + c; seg[i] = v & 0xffu; c = v >> 8; }
+        uint32_t out_carry = 0;                                  // what leaves segment 0: into the next tile
+        for (;;) {
+            cout[t] = c;
+            __syncthreads();
+            const uint32_t into = t < 63 ? cout[t + 1] : 0u;     // from the segment behind (higher positions)
+            out_carry += cout[0];
+            const bool more = __any(into != 0);
+            __syncthreads();
+            if (!more) break;
+            c = into;
+            for (uint32_t i = kFinSeg; c && i-- > 0;) { const uint32_t v = seg[i] + c; seg[i] = v & 0xffu; c = v >> 8; }
         }
+        tile_carry = out_carry;
         __syncthreads();
-        for (uint32_t i = t; i < cnt; i += 64) {
-            const uint32_t at = lo + i;
-            if (at >= P) tail_bytes[at - P] = uint8_t(dig[i]);
-            else if (at < cap) o[at] = uint8_t(dig[i]);
+        for (uint32_t e = t + (pad & ~63u); e < kFinTile; e += 64) {
+            if (e < pad) continue;
+            const uint32_t at = lo + e - pad, v = dig[(e / kFinSeg) * kFinRow + e % kFinSeg];
+            if (at >= P) tail_bytes[at - P] = uint8_t(v);
+            else if (at < cap) o[at] = uint8_t(v);
         }
         hi = lo;
         __syncthreads();
@@ -205,9 +237,8 @@ hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
     uint32_t *fin_pos = reinterpret_cast<uint32_t *>(w);     w += up256(uint64_t(n_slices) * 4);
     uint32_t *S = reinterpret_cast<uint32_t *>(w);
     const K2Plan p{recs, rec_off, n_bins, chunk_base, chunk_slice, out_off};
-    hipError_t e = hipMemsetAsync(S, 0, out_total * 4 + 64, s);
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_k2p_ranges, dim3((n_slices + 63) / 64), dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status);
+    hipLaunchKernelGGL(k_k2p_zero, dim3((total_chunks + 255) / 256), dim3(256), 0, s, p, total_chunks, ck_pos, fin_pos, status, S);
     hipLaunchKernelGGL(k_k2p_code, dim3((total_chunks + 255) / 256), dim3(256), 0, s, p, total_chunks, ck_range, ck_pos, status, S);
     hipLaunchKernelGGL(k_k2p_finish, dim3(n_slices), dim3(64), 0, s, p, fin_range, fin_pos, S, out, out_len, status);
     return hipGetLastError();

@@ -13,7 +13,7 @@ extern "C" {
 // Returns the number of bytes (written up to cap), or SIZE_MAX for a zero-probability bin.  info[0] = chunks,
 // info[1] = bytes emitted before finish(), info[2] = largest digit sum seen, info[3] = carry sent back by finish().
 size_t k2p_emul_encode(const uint16_t *recs, size_t n, uint32_t chunk_bins, uint8_t *out, size_t cap, uint32_t *info) {
-    const auto div = [](uint64_t r, uint32_t t) { return r / t; };
+    const auto div = [](uint64_t r, uint32_t t) { return t ? r / t : 0; };
     const uint32_t cb = chunk_bins ? chunk_bins : kChunk;
     // pass 1: the range recurrence; range and bytes emitted at the start of every chunk
     std::vector<uint64_t> ck_range;
