@@ -389,7 +389,6 @@ __global__ __launch_bounds__(64) void k_range_encode(
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            if (dead) break;
             const uint64_t quot = (VARIANT & 1) ? (tot[k] < 2 ? (tot[k] ? e.range : 0) : div_u64_small(e.range, tot[k], magic[tot[k]]))
                                                 : div_u64_small_f64(e.range, double(tot[k]), inv[k]);
             const uint64_t r1 = quot * pos[k];                   // recode.cpp:826
@@ -397,7 +396,8 @@ __global__ __launch_bounds__(64) void k_range_encode(
             if (!(VARIANT & 2)) e.low += bin[k] ? r0 : 0;
             e.range = bin[k] ? r1 : r0;
             if (e.range < (uint64_t(1) << 51)) {                 // min_range, arithmetic_code.h:61-62,115
-                if (e.range == 0) { st = AVR_SLICE_ZERO_PROB; dead = true; }           // :116-118
+                if (e.range == 0) { st = AVR_SLICE_ZERO_PROB; dead = true; }           // :116-118 (range stays 0 from here on: 0 / total * pos,
+                                                                                     // nothing more is emitted; the chunk loop below ends the walk)
                 else if (VARIANT & 2) do { e.range <<= 8; e.w.n++; } while (e.range < (uint64_t(1) << 55));
                 else do e.emit_digit(); while (e.range < (uint64_t(1) << 55));         // :120-122
             }
