@@ -51,8 +51,11 @@ __device__ __forceinline__ bool eight(const U4 &v, const double *inv, uint64_t &
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) {
         const double i1 = iv[k];
-        // (after a bin of probability zero the rest is skipped: measured faster than walking on, 105 against 118 ms on config 2)
-        ok = ok && bin<WITH_LOW>(low, range, rec[k], [i1](uint64_t r, uint32_t t) { return div_u64_small_f64(r, double(t), i1); }, emit);
+        const auto div = [i1](uint64_t r, uint32_t t) { return div_u64_small_f64(r, double(t), i1); };
+        // pass 1 leaves the walk at a bin of probability zero (measured faster than walking on: 105 against 118 ms on
+        // config 2); pass 2 only sees slices that have none, and a test per bin is what it can do without
+        if (WITH_LOW) bin<true>(low, range, rec[k], div, emit);
+        else ok = ok && bin<false>(low, range, rec[k], div, emit);
     }
     return ok;
 }
