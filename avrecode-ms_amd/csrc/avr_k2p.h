@@ -56,6 +56,27 @@ AVR_K2P_HD bool bin(uint64_t &low, uint64_t &range, uint32_t rec, Div &&div, Emi
     return true;
 }
 
+// The range recurrence alone, without a branch: the number of 8-bit shifts a renormalisation takes (arithmetic_code.h:115-122:
+// below 2^51, shift until 2^55 is reached) follows from the position of the range's top bit, k = (62 - msb) / 8.  Pass 1 is
+// one dependent chain of these per slice, and every branch on it costs more than the few operations that replace it.
+// `bytes` counts the shifts; returns false for a bin of probability zero (the range is 0 then and stays 0).
+template <class Div>
+AVR_K2P_HD bool range_step(uint64_t &range, uint32_t &bytes, uint32_t rec, Div &&div) {
+    const uint32_t pos = (rec >> 1) & 0x7fu, total = pos + ((rec >> 8) & 0x7fu);                 // recode.cpp:825
+    const uint32_t b = total ? rec & 1u : 0u;
+    const uint64_t r1 = div(range, total) * pos;       // recode.cpp:826
+    const uint64_t r = b ? r1 : range - r1;            // arithmetic_code.h:108-114
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t msb = 63u - uint32_t(__clzll(r | 1));
+#else
+    const uint32_t msb = 63u - uint32_t(__builtin_clzll(r | 1));
+#endif
+    const uint32_t k = r < kMinRange ? (62u - msb) >> 3 : 0u;
+    range = r << (8 * k);
+    bytes += r ? k : 0u;
+    return r != 0;
+}
+
 // What is left of a chunk's low, as kTail bytes behind the ones it emitted (byte j: bits 62 - 8j .. 55 - 8j of low, the
 // first with the carry bit on top, the last with the seven bits that remain, shifted up by one).
 template <class Emit>

@@ -73,10 +73,25 @@ __global__ __launch_bounds__(64) void k_k2p_ranges(K2Plan p, uint32_t n_slices, 
     const uint32_t n = p.n_bins[s], c0 = p.chunk_base[s];
     const U4 *r = reinterpret_cast<const U4 *>(p.recs + p.rec_off[s]);
     const uint32_t n_groups = (n + 7) >> 3, last = n_groups ? n_groups - 1 : 0;
-    uint64_t range = kOne, low = 0;                              // arithmetic_code.h:96-97
+    uint64_t range = kOne;                                       // arithmetic_code.h:96-97
     uint32_t pos = 0;
-    bool ok = true;                                              // a bin of probability zero puts the slice in error and ends the walk
-    auto count = [&](uint32_t) { pos++; };
+    bool ok = true;                                              // sticky: a bin of probability zero puts the slice in error
+    // eight records: operands first (they depend on the records alone), then the chain -- range_step, no branch in it
+    auto group = [&](const U4 &v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t rec[8];
+        double iv[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            rec[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+            iv[k] = inv[((rec[k] >> 1) & 0x7fu) + ((rec[k] >> 8) & 0x7fu)];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const double i1 = iv[k];
+            ok &= range_step(range, pos, rec[k], [i1](uint64_t r, uint32_t t) { return div_u64_small_f64(r, double(t), i1); });
+        }
+    };
     // A cache line of records (four groups) per trip, two lines in flight ahead of the chain; every load is unconditional
     // (the index clamped to the slice's last group: what a clamped load returns is never coded).
     auto line = [&](uint32_t g, U4 v[4]) {
@@ -85,15 +100,18 @@ __global__ __launch_bounds__(64) void k_k2p_ranges(K2Plan p, uint32_t n_slices, 
     };
     U4 cur[4], nx1[4];
     if (n_groups) { line(0, cur); line(4, nx1); }
-    for (uint32_t g = 0; g < n_groups && ok; g += 4) {
+    uint32_t g = 0;
+    for (; g + 4 <= n_groups; g += 4) {
         U4 nx2[4];
         line(g + 8, nx2);
         if ((g & (kChunk / 8 - 1)) == 0) { ck_range[c0 + (g >> 7)] = range; ck_pos[c0 + (g >> 7)] = pos; }
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++)
-            if (g + k < n_groups && ok) ok = eight<false>(cur[k], inv, low, range, count);
+        group(cur[0]); group(cur[1]); group(cur[2]); group(cur[3]);
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) { cur[k] = nx1[k]; nx1[k] = nx2[k]; }
+    }
+    if (g < n_groups) {                                          // the slice's last, partial line (chunks start on whole lines)
+        if ((g & (kChunk / 8 - 1)) == 0) { ck_range[c0 + (g >> 7)] = range; ck_pos[c0 + (g >> 7)] = pos; }
+        for (uint32_t k = 0; g + k < n_groups; k++) group(cur[k]);
     }
     if (n_groups == 0) { ck_range[c0] = range; ck_pos[c0] = 0; }  // an empty slice still has its one chunk
     fin_range[s] = range;

@@ -22,7 +22,12 @@ size_t k2p_emul_encode(const uint16_t *recs, size_t n, uint32_t chunk_bins, uint
     uint32_t p = 0;
     for (size_t i = 0; i < n; i++) {
         if (i % cb == 0) { ck_range.push_back(range); ck_pos.push_back(p); }
-        if (!bin<false>(dummy, range, recs[i], div, [&](uint32_t) { p++; })) return SIZE_MAX;
+        // the branch-free form the kernel's pass 1 uses, checked against bin<false> on the fly
+        uint64_t r2 = range;
+        uint32_t p2 = p;
+        const bool ok2 = range_step(r2, p2, recs[i], div);
+        if (!bin<false>(dummy, range, recs[i], div, [&](uint32_t) { p++; })) return ok2 ? SIZE_MAX - 2 : SIZE_MAX;
+        if (!ok2 || r2 != range || p2 != p) return SIZE_MAX - 2;
     }
     const uint32_t P = p;
     // pass 2: every chunk from low = 0, its bytes added into the sums
