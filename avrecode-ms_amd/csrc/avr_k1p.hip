@@ -359,7 +359,9 @@ __global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks
 // per chunk at under five waves per SIMD, are short of waves themselves: every kernel of a half got slower by more
 // than the overlap gave back, 2.05 against 1.95 ms per step.  Also without effect: twice the read-ahead (end positions
 // eight chunks ahead, windows four), and whole-byte look-ups without the arithmetic on n between them -- a step is the
-// hottest lane's seven or so dependent LDS round trips, and neither its loads nor its VALU work.)
+// hottest lane's seven or so dependent LDS round trips, and neither its loads nor its VALU work.  The step as it stands --
+// four look-ups without a branch, four more if any lane needs them, one shift-add between two look-ups -- is 3 % faster
+// than the loops it replaced; taking out, for the measurement, the stores, or the window loads, changes nothing.)
 constexpr uint32_t kChainLanes = 22, kChainWaves = 8;         // kChainLanes: the fewest lanes a wave takes
 __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint32_t n_slices, uint32_t groups, uint32_t chain_lanes, const int32_t *status,
                                                       const uint8_t *tng, const uint32_t *lbits, const uint16_t *lend,
@@ -392,7 +394,6 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
     uint2 e0 = ends(), e1 = ends(), e2 = ends(), e3 = ends();
     uint4 w0 = window(bw_ahead, e0.x), w1 = window(bw_ahead + 32, e1.x);
     bw_ahead += 64;
-#pragma unroll 4
     for (uint32_t c = 0; c < nc; c++) {
         const uint2 e4 = ends();
         const uint4 w2 = window(bw_ahead, e2.x);
@@ -401,25 +402,43 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
         eo += row4;
         uint32_t pos = e0.x;
         const uint32_t end = e0.y;
-        if (pos < end && st < 126) {                             // pStateIdx 63 never moves
-            auto walk32 = [&](uint32_t avail) {                  // up to 32 bins from `pos`
-                uint32_t left = end - pos < 32u ? end - pos : 32u;
-                pos += left;
-                do {
+        // The step is a chain of dependent look-ups, and every branch on it costs about as much as a look-up: the first 32
+        // bins are four look-ups without one (a look-up of n = 0 bins is the identity: rows 0 .. 127 of the table), the next
+        // 32 four more if any lane of the wave has them; what is left after 64 -- rare -- goes the general way.
+        uint32_t left = (end > pos && st < 126) ? end - pos : 0u;    // pStateIdx 63 never moves
+        const uint32_t sh = pos & 31u;
+        auto four = [&](uint32_t avail) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) {
+                const uint32_t n = left < 8u ? left : 8u;
+                uint32_t off = (128u << n) - 128u + (avail & ((1u << n) - 1u));         // all of the index that does not wait for the state
+                asm volatile("" : "+v"(off));                                          // (kept whole: the compiler would split it up again)
+                st = tn[(st << n) + off];                                              // ... and the one shift-add that does
+                avail >>= 8;
+                left -= n;
+            }
+        };
+        four(__builtin_amdgcn_alignbit(w0.y, w0.x, sh));
+        if (__any(left != 0)) {
+            four(__builtin_amdgcn_alignbit(w0.z, w0.y, sh));
+            if (__any(left != 0)) {
+                pos += 64;
+                uint32_t avail = __builtin_amdgcn_alignbit(w0.w, w0.z, sh);      // bins 64 .. 95 are in the window as well
+                uint32_t have = 32;
+                while (left) {
+                    if (have == 0) {                             // a run of more than 96 bins: fetch as it goes
+                        const uint4 win = window(bw_cur, pos);
+                        avail = __builtin_amdgcn_alignbit(win.y, win.x, pos & 31u);
+                        have = 32;
+                    }
                     const uint32_t n = left < 8u ? left : 8u;
-                    st = tn[(128u << n) - 128u + ((st << n) | (avail & ((1u << n) - 1u)))];
+                    uint32_t off = (128u << n) - 128u + (avail & ((1u << n) - 1u));
+                    asm volatile("" : "+v"(off));
+                    st = tn[(st << n) + off];
                     avail >>= 8;
-                    left -= n;
-                } while (left);
-            };
-            auto walk = [&](const uint4 &win) {                  // up to 96 bins from `pos`, out of a 128-bit window
-                const uint32_t sh = pos & 31u;
-                walk32(__builtin_amdgcn_alignbit(win.y, win.x, sh));
-                if (pos < end) walk32(__builtin_amdgcn_alignbit(win.z, win.y, sh));
-                if (pos < end) walk32(__builtin_amdgcn_alignbit(win.w, win.z, sh));
-            };
-            walk(w0);                                            // the window requested two chunks ago
-            while (pos < end) walk(window(bw_cur, pos));         // a run of more than 96 bins: fetch as it goes
+                    left -= n; pos += n; have -= 8;
+                }
+            }
         }
         bw_cur += 32;
         e0 = e1; e1 = e2; e2 = e3; e3 = e4;
