@@ -143,8 +143,8 @@ def cpu_baseline(avr, workload, kind, n_slices, first_slice, gpu_bytes_of, budge
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument("--kind", default="cabac", choices=["cabac", "range"])
     ap.add_argument("--slices", type=int, default=0, help="slices per rank (default: the configuration's own count)")
