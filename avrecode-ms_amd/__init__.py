@@ -16,6 +16,7 @@ The directory name contains a hyphen (it follows the reference's repository name
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import shutil
@@ -26,6 +27,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint8
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libavrecode_hip.so")
+HOOKS_LIB_PATH = os.path.join(_HERE, "libavrecode_hip_hooks.so")   # -DAVR_TEST_HOOKS build, for tests/ only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avrecode_ms_amd.h")
 
 KIND_CABAC, KIND_RANGE, KIND_CABAC_CODES = 0, 1, 2
@@ -43,22 +45,36 @@ class AvrError(RuntimeError):
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP kernels and the C ABI for gfx950 into libavrecode_hip.so (in-tree)."""
+    """Compile the HIP kernels and the C ABI for gfx950 (in-tree): libavrecode_hip.so, the product, and
+    libavrecode_hip_hooks.so, the same sources with -DAVR_TEST_HOOKS (the switches tests/ use to force rare paths;
+    the product library has no such switch).  One hipcc per source file, in parallel."""
     deps = [os.path.join(_CSRC, d) for d in _DEPS] + [HEADER_PATH]
-    if not force and os.path.exists(LIB_PATH):
-        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(HOOKS_LIB_PATH):
+        if all(min(os.path.getmtime(LIB_PATH), os.path.getmtime(HOOKS_LIB_PATH)) >= os.path.getmtime(d) for d in deps):
             return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         if os.path.exists(LIB_PATH):      # GPU box without a compiler in PATH: use the shipped build
             return LIB_PATH
         raise AvrError("hipcc not found and no prebuilt libavrecode_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-o", LIB_PATH + ".tmp"] + [os.path.join(_CSRC, s) for s in _SOURCES]
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"]
+    jobs = []
+    for variant, extra in (("", []), (".hooks", ["-DAVR_TEST_HOOKS"])):
+        for src in _SOURCES:
+            obj = os.path.join(objdir, src + variant + ".o")
+            jobs.append((obj, [hipcc] + flags + extra + ["-c", "-o", obj, os.path.join(_CSRC, src)]))
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+        for _, cmd in jobs:
+            print(" ".join(cmd))
+    procs = [subprocess.Popen(cmd) for _, cmd in jobs]
+    if any(p.wait() != 0 for p in procs):
+        raise AvrError("hipcc failed")
+    for variant, path in (("", LIB_PATH), (".hooks", HOOKS_LIB_PATH)):
+        objs = [os.path.join(objdir, src + variant + ".o") for src in _SOURCES]
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", path + ".tmp"] + objs, check=True)
+        os.replace(path + ".tmp", path)
     return LIB_PATH
 
 
@@ -175,28 +191,59 @@ SIGNATURES = {
 }
 
 
+def _load(path):
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7; loading it first
+    # makes the dynamic linker bind this library to the same copy (same SONAME), which is
+    # required anyway since device pointers and streams are shared with torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    try:
+        handle = ctypes.CDLL(path)
+    except OSError as exc:
+        raise AvrError(f"cannot load the HIP extension {path}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)          # AttributeError = a declared symbol is missing
+        fn.restype, fn.argtypes = res, args
+    return handle
+
+
 def lib():
     """Load libavrecode_hip.so (building it first if a compiler is present). Raises if absent."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build_native()
-        # One HIP runtime per process: torch bundles its own libamdhip64.so.7; loading it first
-        # makes the dynamic linker bind this library to the same copy (same SONAME), which is
-        # required anyway since device pointers and streams are shared with torch.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        try:
-            handle = ctypes.CDLL(LIB_PATH)
-        except OSError as exc:
-            raise AvrError(f"cannot load the HIP extension {LIB_PATH}: {exc}") from exc
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)          # AttributeError = a declared symbol is missing
-            fn.restype, fn.argtypes = res, args
-        _lib = handle
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+_hooks_lib = None
+
+
+@contextlib.contextmanager
+def test_hooks(**hooks):
+    """FOR tests/ ONLY.  Inside the block, lib() is libavrecode_hip_hooks.so -- the same sources built with
+    -DAVR_TEST_HOOKS -- with the named hooks set (csrc/avr_internal.h: k1p_force_retry_every, census_stride,
+    chain_lanes, k1_form_norm, k1_path [1 serial, 2 chunked], no_dense, no_hint); all of them keep the bytes exact and
+    only force paths that real batches take rarely.  The product library has no such switches."""
+    global _lib, _hooks_lib
+    if _hooks_lib is None:
+        if not os.path.exists(HOOKS_LIB_PATH):
+            build_native()
+        _hooks_lib = _load(HOOKS_LIB_PATH)
+        _hooks_lib.avr_test_hook_set.restype, _hooks_lib.avr_test_hook_set.argtypes = c_int, [c_char_p, c_uint32]
+    saved, _lib = _lib, _hooks_lib
+    try:
+        _hooks_lib.avr_test_hook_set(b"reset", 0)
+        for name, value in hooks.items():
+            if _hooks_lib.avr_test_hook_set(name.encode(), int(value)) != 0:
+                raise AvrError(_hooks_lib.avr_last_error().decode())
+        yield _hooks_lib
+    finally:
+        _hooks_lib.avr_test_hook_set(b"reset", 0)
+        _lib = saved
 
 
 def _check(rc: int) -> int:

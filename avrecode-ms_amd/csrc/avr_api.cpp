@@ -161,7 +161,42 @@ static int stage_h2d(avr_batch *b, T *dst, const T *src, size_t n) {
     AVR_HIP(hipMemcpyAsync(dst, b->h_plan.p + at, bytes, hipMemcpyHostToDevice, b->stream));
     return AVR_OK;
 }
+namespace avr {
+// the three environment switches of the library (avr_internal.h), read once
+const Env &env() {
+    static const Env e = [] {
+        Env v{0, false, false};
+        if (const char *p = getenv("AVR_K1_PATH")) v.k1_path = strcmp(p, "chunked") == 0 ? 2 : strcmp(p, "serial") == 0 ? 1 : 0;
+        v.no_dense = getenv("AVR_NO_DENSE") != nullptr;
+        v.no_hint = getenv("AVR_BATCH_NO_HINT") != nullptr;
+        return v;
+    }();
+    return e;
+}
+#ifdef AVR_TEST_HOOKS
+TestHooks &test_hooks() { static TestHooks h{}; return h; }
+#endif
+}  // namespace avr
+
 extern "C" {
+
+#ifdef AVR_TEST_HOOKS
+// Test build only (libavrecode_hip_hooks.so): set a hook by name; returns AVR_ERR_INVALID for an unknown name.
+int avr_test_hook_set(const char *name, uint32_t value) {
+    avr::TestHooks &h = avr::test_hooks();
+    if (!name) return fail(AVR_ERR_INVALID, "null hook name");
+    if (!strcmp(name, "k1p_force_retry_every")) h.k1p_force_retry_every = value;
+    else if (!strcmp(name, "census_stride")) h.census_stride = value;
+    else if (!strcmp(name, "chain_lanes")) h.chain_lanes = value;
+    else if (!strcmp(name, "k1_form_norm")) h.k1_form_norm = value;
+    else if (!strcmp(name, "k1_path")) h.k1_path = value;
+    else if (!strcmp(name, "no_dense")) h.no_dense = value;
+    else if (!strcmp(name, "no_hint")) h.no_hint = value;
+    else if (!strcmp(name, "reset")) h = avr::TestHooks{};
+    else return fail(AVR_ERR_INVALID, "unknown test hook %s", name);
+    return AVR_OK;
+}
+#endif
 
 const char *avr_last_error(void) { return g_err; }
 const char *avr_version(void) { return "avrecode-ms_amd 0.1 (gfx950)"; }
@@ -320,7 +355,7 @@ static int submit_codes(avr_batch *b, uint32_t n32) {
     }
     // few, long slices: the intra-slice parallel kernels; many short ones: one lane per slice (same rule as for records)
     bool chunked = n <= 32768 && b->total_bins / n >= 8192;
-    if (const char *force = getenv("AVR_K1_PATH")) chunked = strcmp(force, "chunked") == 0;
+    if (avr::k1_path()) chunked = avr::k1_path() == 2;
     std::vector<uint32_t> order;
     if (!chunked) {
         std::vector<uint64_t> tile_off;
@@ -388,7 +423,7 @@ static int submit_impl(avr_batch *b, bool use_hint) {
     // One lane per slice needs tens of thousands of slices to fill the chip; a batch of few, long
     // slices (a clip with one slice per frame) goes through the intra-slice parallel kernels.
     bool chunked = n <= 32768 && b->total_bins / n >= 8192;
-    if (const char *force = getenv("AVR_K1_PATH")) chunked = strcmp(force, "chunked") == 0;
+    if (avr::k1_path()) chunked = avr::k1_path() == 2;
     b->last_path = chunked;
 
     int rc;
@@ -509,7 +544,7 @@ int avr_batch_submit(avr_batch *b) {
     const size_t n = b->n_bins.size();
     b->dense_off.assign(n + 1, 0);
     if (n == 0) { b->in_flight = true; return AVR_OK; }
-    const bool use_hint = b->dense_hint > 0 && !getenv("AVR_BATCH_NO_HINT");
+    const bool use_hint = b->dense_hint > 0 && !avr::no_hint();
     if (int rc = submit_impl(b, use_hint)) { (void)hipStreamSynchronize(b->stream); return rc; }
     b->in_flight = true;
     return AVR_OK;

@@ -21,6 +21,33 @@
 
 namespace avr {
 
+// Run-time switches of the library.
+//   * Environment, read ONCE per process (env()), documented in include/avrecode_ms_amd.h; none of them can change a
+//     coded byte -- they choose between mappings that produce the same bytes:
+//       AVR_K1_PATH=serial|chunked   force one lane per slice / the intra-slice parallel kernels in the batch API
+//       AVR_NO_DENSE=1               one-lane-per-slice K1 without the renumbering onto the contexts the batch uses
+//       AVR_BATCH_NO_HINT=1          avr_batch_submit always asks the device for the context count (and waits)
+//   * Test hooks, compiled in only with -DAVR_TEST_HOOKS (libavrecode_hip_hooks.so, which tests/ load; the product
+//     library has neither the setter nor any code that reads them): force the hand-over paths that real streams
+//     take once in a blue moon, so that every run of the tests proves them.  All bit-exact as well.
+struct Env { int k1_path; bool no_dense, no_hint; };             // k1_path: 0 auto, 1 serial, 2 chunked
+const Env &env();
+struct TestHooks {
+    uint32_t k1p_force_retry_every;  // k_k1p_d hands every n-th slice to the serial kernel (0 = off)
+    uint32_t census_stride;          // sampling stride of both census kernels (0 = the built-in 16)
+    uint32_t chain_lanes;            // lanes per wave of k_k1p_ctxchain (0 = by batch shape)
+    uint32_t k1_form_norm;           // one-lane-per-slice K1 in normalised form (CabacLaneN)
+    uint32_t k1_path, no_dense, no_hint;   // the environment switches above, settable per test (non-zero wins over env())
+};
+#ifdef AVR_TEST_HOOKS
+TestHooks &test_hooks();
+#else
+inline const TestHooks &test_hooks() { static const TestHooks none{}; return none; }
+#endif
+inline int k1_path() { return test_hooks().k1_path ? int(test_hooks().k1_path) : env().k1_path; }
+inline bool no_dense() { return test_hooks().no_dense || env().no_dense; }
+inline bool no_hint() { return test_hooks().no_hint || env().no_hint; }
+
 // How many LDS rows the renumbered contexts of a batch need is known on the device after the census; the launches
 // that follow are sized by it, which costs the host one 4-byte round trip per call.  A caller that has a good guess
 // (the batch API: the count of its previous batch) passes it here: the launches are sized by `rows`, nothing waits,

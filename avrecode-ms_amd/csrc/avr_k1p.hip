@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256) void k_k1p_d(Plan p, const SliceTotals *tot, c
     const uint32_t s = blockIdx.x, t = threadIdx.x;
     if (status[s] != AVR_SLICE_OK) { if (t == 0 && status[s] != AVR_SLICE_DONE) out_len[s] = 0; return; }   // DONE: coded by the pass before
     const SliceTotals T = tot[s];
-    // force_retry_every (test switch AVR_K1P_FORCE_RETRY=n, 0 = off): every n-th slice is handed to the serial
+    // force_retry_every (test hook k1p_force_retry_every = n, 0 = off; always 0 in the product library): every n-th slice is handed to the serial
     // kernel as if phase D had met the carry pattern it does not resolve -- the hand-over is then proven on
     // every run of the tests, not only when that pattern occurs
     if (T.bad || (force_retry_every && s % force_retry_every == 0)) { if (t == 0) status[s] = AVR_SLICE_RETRY_SERIAL; return; }
@@ -1177,10 +1177,7 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
         // issuing the waves becomes the limit (measured on 512 slices x 86 contexts: 8 lanes 0.77 ms, 16 0.44, 22 .. 64 0.29)
         uint32_t chain_lanes = uint32_t((uint64_t(n_slices) * n_states + 2047) / 2048);
         chain_lanes = chain_lanes < kChainLanes ? kChainLanes : chain_lanes > 64 ? 64 : chain_lanes;
-        if (const char *f = getenv("AVR_CHAIN_LANES")) {         // tuning switch
-            const uint32_t v = uint32_t(strtoul(f, nullptr, 10));
-            if (v >= 1 && v <= 64) chain_lanes = v;
-        }
+        if (const uint32_t v = test_hooks().chain_lanes) chain_lanes = v <= 64 ? v : 64;     // tuning switch (test build)
         const uint32_t groups = (n_states + chain_lanes - 1) / chain_lanes;
         hipLaunchKernelGGL(k_k1p_ctxchain, dim3((n_slices * groups + kChainWaves - 1) / kChainWaves), dim3(64 * kChainWaves), 0, s, p,
                            n_slices, groups, chain_lanes, status, tn, lbits, lend, init_states, est, final_states);
@@ -1220,8 +1217,7 @@ static hipError_t launch_code(hipStream_t s, const Plan &p, uint32_t n_slices, c
     hipLaunchKernelGGL(k_k1p_b2, dim3(n_slices), dim3(256), 0, s, p, status, st, en, tot, S);
     if (tile_codes) hipLaunchKernelGGL(k_k1p_c<true>, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
     else hipLaunchKernelGGL(k_k1p_c<false>, dim3(chunk_blocks), dim3(256), 0, s, p, pl->total_chunks, res, st, en, tot, S);
-    uint32_t force_retry_every = 0;                              // test switch, see k_k1p_d
-    if (const char *f = getenv("AVR_K1P_FORCE_RETRY")) force_retry_every = uint32_t(strtoul(f, nullptr, 10));
+    const uint32_t force_retry_every = test_hooks().k1p_force_retry_every;   // test build only, see k_k1p_d
     hipLaunchKernelGGL(k_k1p_d, dim3(n_slices), dim3(256), 0, s, p, tot, S, out, out_off, out_len, status, force_retry_every);
     return hipGetLastError();
 }
@@ -1257,8 +1253,7 @@ size_t k1p_workspace_bytes(size_t n_slices, uint32_t n_states, const avr_chunk_p
 constexpr uint32_t kK1pCensusStride = 16;
 
 static uint32_t census_stride() {
-    const char *cs = getenv("AVR_CENSUS_STRIDE");
-    return cs && atoi(cs) > 0 ? uint32_t(atoi(cs)) : kK1pCensusStride;
+    return test_hooks().census_stride ? test_hooks().census_stride : kK1pCensusStride;
 }
 
 // One pass of the whole path over the slices whose status is AVR_SLICE_OK.

@@ -77,6 +77,76 @@ AVR_K2P_HD bool range_step(uint64_t &range, uint32_t &bytes, uint32_t rec, Div &
     return r != 0;
 }
 
+// ------------------------------------------------------------------ the range recurrence in double precision (pass 1, round 3)
+//
+// Pass 1 is one dependent chain per slice, and on this chip EVERY dependent instruction of a lone wave costs 8-11 cycles
+// whatever it is (measured, tools/ubench/chain_latency.hip: v_fma_f64 9.0, v_trunc_f64 8.2, v_mad_u64_u32 10.7,
+// v_lshlrev_b64 10.1, v_add_u32 8.9, s_mul_hi_u32 9.0, s_lshl_b64 8.4): what counts is the NUMBER of dependent
+// instructions per bin.  The 64-bit integer form above needs about 24 (64-bit shift, two conversions to double, the
+// two-step quotient, two conversions back, two 32 x 32 -> 64 multiplies, a subtract with borrow, a select, count
+// leading zeros and its arithmetic, a compare); this form needs 12, all on the double-precision pipe:
+//
+//   range = H * 2^32 + L exactly, H and L integers held in doubles, H >= 0, |L| <= 2^47 (a REDUNDANT pair: L is signed
+//   and need not be below 2^32).  With inv = fl(1 / total), h = inv / 2 (avr_div.h), ps = +pos for a 1, -pos for a 0,
+//   nb = 0 for a 1, 1 for a 0:
+//      qh = trunc(fma(H, inv, h))                 H / total                      (exact: H < 2^44)
+//      rh = fma(-qh, total, H)                    its remainder, < total
+//      a  = fma(rh, 2^32, L)                      |a| < 2^48: exact
+//      ql = floor(fma(a, inv, h))                 a / total, rounded down; exact for |a| < 2^51: (a + 1/2) / total is at least
+//                                                 1 / (2 total) away from an integer, the two roundings move it by |a / total| 2^-52
+//   => range / total = qh * 2^32 + ql (recode.cpp:826), and the new range nb * range + (range / total) * ps
+//      (arithmetic_code.h:107-114) limb by limb:   H1 = fma(qh, ps, nb * H),  L1 = fma(ql, ps, nb * L)   (|L1| < 2^48)
+//      v  = fma(H1, 2^32, L1)                     the new range as ONE double: exact when it is below 2^53, and rounding is
+//                                                 monotone, so v < 2^51 (and v < 2^47) decide exactly what the reference's
+//                                                 comparisons decide (arithmetic_code.h:115-122): shift by 0, 8 or 16 bits
+//      cL = (L1 + 1.5 * 2^84) - 1.5 * 2^84        L1 rounded to a multiple of 2^32 (the adder's own rounding)
+//      Hn = fma(cL, 2^-32, H1),  Ln = L1 - cL     the same value with |Ln| <= 2^31
+//      H = Hn * s,  L = Ln * s                    s = 1, 2^8 or 2^16: |L| <= 2^47
+// The comparison and the carry run side by side: the chain is t1, qh, rh, a, t2, ql, L1, v | t, cmp | cL, select, Hn, H.
+// A new range below 2^39 (three or more bytes at once -- only a record with pos or neg 0 does that -- or zero: a bin of
+// probability zero) is outside what the two thresholds cover: vmin_hi notes it and the slice takes the integer form above.
+struct RangeFP { double H, L; };
+struct BinFP { double inv, h, d, ps, nb; };
+constexpr double kTwo32 = 4294967296.0, kInvTwo32 = 1.0 / 4294967296.0;
+constexpr double kSplit32 = 1.5 * 4294967296.0 * 4294967296.0 * 1048576.0;    // 1.5 * 2^84: ulp 2^32
+constexpr double kTwo51 = 2251799813685248.0, kTwo47 = 140737488355328.0, kTwo39 = 549755813888.0;
+
+AVR_K2P_HD RangeFP fp_from_u64(uint64_t r) { return RangeFP{double(uint32_t(r >> 32)), double(uint32_t(r))}; }
+AVR_K2P_HD uint64_t fp_to_u64(const RangeFP &r) { return (uint64_t(r.H) << 32) + uint64_t(int64_t(r.L)); }
+// the operands of a record (the kernel reads them from two small tables instead)
+AVR_K2P_HD BinFP fp_operands(uint32_t rec) {
+    const uint32_t pos = (rec >> 1) & 0x7fu, total = pos + ((rec >> 8) & 0x7fu), b = total ? rec & 1u : 0u;
+    const double inv = total ? 1.0 / double(total) : 0.0;
+    return BinFP{inv, 0.5 * inv, double(total), b ? double(pos) : -double(pos), b ? 0.0 : 1.0};
+}
+// The constants of a step, as VALUES: the kernel keeps them in scalar registers (a 32-bit literal forces the compiler into
+// the two-operand form of the multiply-add, which overwrites an input that is still needed: a register copy per use).
+struct FpConsts { double two32, inv_two32, split32, two51, two47; };
+AVR_K2P_HD FpConsts fp_consts() { return FpConsts{kTwo32, kInvTwo32, kSplit32, kTwo51, kTwo47}; }
+AVR_K2P_HD uint32_t fp_hi(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return uint32_t(u >> 32); }
+constexpr uint32_t kTwo39Hi = 0x42600000u;             // the high word of 2^39 as a double: fp_hi(v) < this iff 0 <= v < 2^39
+
+// One bin; returns the number of BITS shifted out (0, 8, 16).  vmin_hi: the high word of the smallest new range seen (the
+// new range is never negative, so the high words of the doubles order like the values).
+AVR_K2P_HD uint32_t range_step_fp(RangeFP &r, uint32_t &vmin_hi, const BinFP &o, const FpConsts &K) {
+    const double qh = __builtin_trunc(__builtin_fma(r.H, o.inv, o.h));
+    const double rh = __builtin_fma(-qh, o.d, r.H);
+    const double H1 = __builtin_fma(qh, o.ps, r.H * o.nb);
+    const double a = __builtin_fma(rh, K.two32, r.L);
+    const double ql = __builtin_floor(__builtin_fma(a, o.inv, o.h));
+    const double L1 = __builtin_fma(ql, o.ps, r.L * o.nb);
+    const double v = __builtin_fma(H1, K.two32, L1);
+    const double t = L1 + K.split32;
+    const double cL = t - K.split32;
+    const double Hn = __builtin_fma(cL, K.inv_two32, H1), Ln = L1 - cL;
+    const int sh = v < K.two51 ? (v < K.two47 ? 16 : 8) : 0;
+    r.H = __builtin_ldexp(Hn, sh);
+    r.L = __builtin_ldexp(Ln, sh);
+    const uint32_t vh = fp_hi(v);
+    vmin_hi = vh < vmin_hi ? vh : vmin_hi;
+    return uint32_t(sh);
+}
+
 // What is left of a chunk's low, as kTail bytes behind the ones it emitted (byte j: bits 62 - 8j .. 55 - 8j of low, the
 // first with the carry bit on top, the last with the seven bits that remain, shifted up by one).
 template <class Emit>

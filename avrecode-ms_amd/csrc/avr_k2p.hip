@@ -1,7 +1,8 @@
 // K2p kernels: the recoded range coder (compress direction) for batches of few, long slices.  The decomposition and the
 // per-lane functions are in avr_k2p.h; this file maps them to lanes:
 //
-//   k_k2p_ranges   pass 1   lane per slice       the range recurrence; range and bytes emitted at every chunk start
+//   k_k2p_ranges_fp pass 1  lane per slice       the range recurrence (double-precision form); range and bytes emitted at every chunk start
+//   k_k2p_ranges   pass 1   lane per slice       the same in 64-bit integers: the slices the first form hands over (rare)
 //   k_k2p_code     pass 2   lane per chunk       the coder from (low = 0, noted range); bytes added into 32-bit sums
 //   k_k2p_finish   pass 3   workgroup per slice  carries from the last byte, finish(), bytes out
 //
@@ -18,6 +19,7 @@
 namespace avr {
 
 using namespace k2p;
+static_assert(k2p::kChunk == AVR_CHUNK_BINS, "the chunk plan of the C ABI is made for this chunk size");
 
 namespace {
 
@@ -64,12 +66,14 @@ __device__ __forceinline__ bool eight(const U4 &v, const double *inv, uint64_t &
 // begins; fin_range / fin_pos: at the slice's end.  A zero-probability bin (arithmetic_code.h:116-118) ends the slice
 // with AVR_SLICE_ZERO_PROB.
 __global__ __launch_bounds__(64) void k_k2p_ranges(K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
-                                                  uint64_t *fin_range, uint32_t *fin_pos, int32_t *status) {
+                                                  uint64_t *fin_range, uint32_t *fin_pos, int32_t *status, int32_t want_status) {
     __shared__ double inv[256];
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    const bool mine = s < n_slices && status[s] == want_status;
+    if (!__syncthreads_or(mine)) return;                         // the usual case when this is the hand-over launch: nothing to do
     fill_inv(inv);
     __syncthreads();
-    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= n_slices || status[s] != AVR_SLICE_OK) return;
+    if (!mine) return;
     const uint32_t n = p.n_bins[s], c0 = p.chunk_base[s];
     const U4 *r = reinterpret_cast<const U4 *>(p.recs + p.rec_off[s]);
     const uint32_t n_groups = (n + 7) >> 3, last = n_groups ? n_groups - 1 : 0;
@@ -116,7 +120,90 @@ __global__ __launch_bounds__(64) void k_k2p_ranges(K2Plan p, uint32_t n_slices, 
     if (n_groups == 0) { ck_range[c0] = range; ck_pos[c0] = 0; }  // an empty slice still has its one chunk
     fin_range[s] = range;
     fin_pos[s] = pos;
-    if (!ok) status[s] = AVR_SLICE_ZERO_PROB;
+    status[s] = ok ? AVR_SLICE_OK : AVR_SLICE_ZERO_PROB;
+}
+
+// A slice whose region is too small for what passes 2 and 3 write (they ADD into the 32-bit sums at positions up to fin_pos +
+// kTail, without a bound of their own) is taken out here: AVR_SLICE_OVERFLOW, instead of sums spilling into the next slice.
+__global__ __launch_bounds__(256) void k_k2p_fits(K2Plan p, uint32_t n_slices, const uint32_t *fin_pos, int32_t *status) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_slices || status[s] != AVR_SLICE_OK) return;
+    if (uint64_t(fin_pos[s]) + kTail > p.out_off[s + 1] - p.out_off[s]) status[s] = AVR_SLICE_OVERFLOW;
+}
+
+// Pass 1, double-precision form (range_step_fp, avr_k2p.h): the same chunk notes from a chain of 12 dependent
+// instructions per bin instead of 24.  A record's operands come from two small LDS tables -- by total: { 1 / total,
+// 1 / (2 total), total }, by (pos, bin): { +-pos, bin ? 0 : 1 } -- fetched for eight records before the first of them is
+// walked.  A slice with a new range below 2^39 anywhere (a record with pos or neg 0, or a bin of probability zero) is handed
+// to k_k2p_ranges (status AVR_SLICE_RETRY_SERIAL), which covers everything.  Also validates: bit 15 of a record must be clear.
+struct TotEntry { double inv, h, d, pad; };
+struct PosEntry { double ps, nb; };
+__global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
+                                                     uint64_t *fin_range, uint32_t *fin_pos, int32_t *status) {
+    __shared__ TotEntry tot_tab[256];
+    __shared__ PosEntry pos_tab[256];
+    for (uint32_t d = threadIdx.x; d < 256; d += 64) {
+        const double inv = d ? 1.0 / double(d) : 0.0;
+        tot_tab[d] = TotEntry{inv, 0.5 * inv, double(d), 0.0};
+        const uint32_t pos = d >> 1, b = d & 1u;
+        pos_tab[d] = PosEntry{b ? double(pos) : -double(pos), b ? 0.0 : 1.0};
+    }
+    __syncthreads();
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_slices || status[s] != AVR_SLICE_OK) return;
+    const uint32_t n = p.n_bins[s], c0 = p.chunk_base[s];
+    const U4 *r = reinterpret_cast<const U4 *>(p.recs + p.rec_off[s]);
+    const uint32_t n_groups = (n + 7) >> 3, last = n_groups ? n_groups - 1 : 0;
+    RangeFP rg = fp_from_u64(kOne);                              // arithmetic_code.h:96-97
+    FpConsts K = fp_consts();
+    asm volatile("" : "+s"(K.two32), "+s"(K.inv_two32), "+s"(K.split32), "+s"(K.two51), "+s"(K.two47));   // in scalar registers, see FpConsts
+    uint32_t vmin_hi = 0xffffffffu;
+    uint32_t pos8 = 0, high = 0;                                 // pos8: BITS shifted out so far
+    auto group = [&](const U4 &v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        high |= (w[0] | w[1]) | (w[2] | w[3]);
+        BinFP o[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            // a padding record (0) reads { -0, 1 }: a 0 of probability one.  Anything else with total 0, or pos 0 and bin 1, makes a
+            // range of zero, which vmin_hi notes.
+            const uint32_t wk = w[k >> 1], sh = 16 * (k & 1);
+            const uint32_t total32 = (((wk >> (sh + 1)) & 0x7fu) + ((wk >> (sh + 8)) & 0x7fu)) << 5;
+            const uint32_t pos16 = sh ? (wk >> 12) & 0xff0u : (wk << 4) & 0xff0u;
+            const TotEntry te = *reinterpret_cast<const TotEntry *>(reinterpret_cast<const uint8_t *>(tot_tab) + total32);
+            const PosEntry pe = *reinterpret_cast<const PosEntry *>(reinterpret_cast<const uint8_t *>(pos_tab) + pos16);
+            o[k] = BinFP{te.inv, te.h, te.d, pe.ps, pe.nb};
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) pos8 += range_step_fp(rg, vmin_hi, o[k], K);
+    };
+    auto note = [&](uint32_t g) { ck_range[c0 + (g >> 7)] = fp_to_u64(rg); ck_pos[c0 + (g >> 7)] = pos8 >> 3; };
+    auto line = [&](uint32_t g, U4 v[4]) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) v[k] = r[g + k < last ? g + k : last];
+    };
+    U4 cur[4], nx1[4];
+    if (n_groups) { line(0, cur); line(4, nx1); }
+    uint32_t g = 0;
+    for (; g + 4 <= n_groups; g += 4) {
+        U4 nx2[4];
+        line(g + 8, nx2);
+        if ((g & (kChunk / 8 - 1)) == 0) note(g);
+        group(cur[0]); group(cur[1]); group(cur[2]); group(cur[3]);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { cur[k] = nx1[k]; nx1[k] = nx2[k]; }
+    }
+    if (g < n_groups) {                                          // the slice's last, partial line (chunks start on whole lines)
+        if ((g & (kChunk / 8 - 1)) == 0) note(g);
+        group(cur[0]);
+        if (g + 1 < n_groups) group(cur[1]);
+        if (g + 2 < n_groups) group(cur[2]);
+    }
+    if (n_groups == 0) { ck_range[c0] = kOne; ck_pos[c0] = 0; }
+    fin_range[s] = fp_to_u64(rg);
+    fin_pos[s] = pos8 >> 3;
+    if (high & 0x80008000u) status[s] = AVR_SLICE_BAD_RECORD;
+    else if (vmin_hi < kTwo39Hi) status[s] = AVR_SLICE_RETRY_SERIAL;   // the integer form walks it again, from the start
 }
 
 // Between the passes: the positions that will be ADDED into are zeroed -- the first kTail of every chunk (where earlier chunks
@@ -258,7 +345,10 @@ hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
     uint32_t *fin_pos = reinterpret_cast<uint32_t *>(w);     w += up256(uint64_t(n_slices) * 4);
     uint32_t *S = reinterpret_cast<uint32_t *>(w);
     const K2Plan p{recs, rec_off, n_bins, chunk_base, chunk_slice, out_off};
-    hipLaunchKernelGGL(k_k2p_ranges, dim3((n_slices + 63) / 64), dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status);
+    hipLaunchKernelGGL(k_k2p_ranges_fp, dim3((n_slices + 63) / 64), dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status);
+    hipLaunchKernelGGL(k_k2p_ranges, dim3((n_slices + 63) / 64), dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status,
+                       AVR_SLICE_RETRY_SERIAL);
+    hipLaunchKernelGGL(k_k2p_fits, dim3((n_slices + 255) / 256), dim3(256), 0, s, p, n_slices, fin_pos, status);
     hipLaunchKernelGGL(k_k2p_zero, dim3((total_chunks + 255) / 256), dim3(256), 0, s, p, total_chunks, ck_pos, fin_pos, status, S);
     hipLaunchKernelGGL(k_k2p_code, dim3((total_chunks + 255) / 256), dim3(256), 0, s, p, total_chunks, ck_range, ck_pos, status, S);
     hipLaunchKernelGGL(k_k2p_finish, dim3(n_slices), dim3(64), 0, s, p, fin_range, fin_pos, S, out, out_len, status);

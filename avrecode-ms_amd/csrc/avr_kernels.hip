@@ -21,7 +21,9 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <mutex>
 #include <type_traits>
+#include <vector>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -333,30 +335,16 @@ __global__ __launch_bounds__(256) void k_k1_census(const void *recs, const uint6
 
 // ------------------------------------------------------------------ K2
 
-// floor(n / d) for n < 2^63 + 1, 2 <= d < 256, by long division over 16-bit digits: each step
-// divides a 24-bit value by d with one multiply-high by m = ceil(2^32 / d), exact because
-// a * (m*d - 2^32) < 2^32 for a < 2^24, d < 2^8.  (The GPU has no integer divide.)
-__device__ __forceinline__ uint64_t div_u64_small(uint64_t n, uint32_t d, uint32_t m) {
-    const uint32_t hi = uint32_t(n >> 32), lo = uint32_t(n);
-    uint32_t a = hi >> 16;
-    const uint32_t q3 = __umulhi(a, m); a = ((a - q3 * d) << 16) | (hi & 0xffffu);
-    const uint32_t q2 = __umulhi(a, m); a = ((a - q2 * d) << 16) | (lo >> 16);
-    const uint32_t q1 = __umulhi(a, m); a = ((a - q1 * d) << 16) | (lo & 0xffffu);
-    const uint32_t q0 = __umulhi(a, m);
-    return (uint64_t((q3 << 16) | q2) << 32) | ((q1 << 16) | q0);
-}
-
-// VARIANT (measurement only, AVR_K2_VARIANT): bit 0 = the integer long division, bit 1 = the range recurrence alone
-// (no low, no digits: the serial floor of this coder).  A deeper read-ahead than two chunks was
-// measured and buys nothing even at one wave per SIMD: the bin-to-bin dependency chain, not HBM latency, is the time.
-template <bool TILED, int VARIANT>
+// A deeper read-ahead than two chunks was measured and buys nothing even at one wave per SIMD: the bin-to-bin
+// dependency chain, not HBM latency, is the time.  (Round 2's measurement variants -- the integer long division above,
+// the range recurrence alone -- are gone from the library: their numbers are in DESIGN.md section 4.)
+template <bool TILED>
 __global__ __launch_bounds__(64) void k_range_encode(
     const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
     uint32_t n_slices, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
-    __shared__ uint32_t magic[256];                              // ceil(2^32 / d)
     __shared__ double inv_d[256];                                // fl(1 / d)
     const uint32_t lane = threadIdx.x;
-    for (uint32_t d = lane; d < 256; d += 64) { magic[d] = d >= 2 ? 0xffffffffu / d + 1 : 0; inv_d[d] = d ? 1.0 / double(d) : 0.0; }
+    for (uint32_t d = lane; d < 256; d += 64) inv_d[d] = d ? 1.0 / double(d) : 0.0;
     __syncthreads();
     const uint32_t g = blockIdx.x * 64 + lane;
     if (g >= n_slices) return;
@@ -389,16 +377,14 @@ __global__ __launch_bounds__(64) void k_range_encode(
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const uint64_t quot = (VARIANT & 1) ? (tot[k] < 2 ? (tot[k] ? e.range : 0) : div_u64_small(e.range, tot[k], magic[tot[k]]))
-                                                : div_u64_small_f64(e.range, double(tot[k]), inv[k]);
+            const uint64_t quot = div_u64_small_f64(e.range, double(tot[k]), inv[k]);
             const uint64_t r1 = quot * pos[k];                   // recode.cpp:826
             const uint64_t r0 = e.range - r1;                    // arithmetic_code.h:108
-            if (!(VARIANT & 2)) e.low += bin[k] ? r0 : 0;
+            e.low += bin[k] ? r0 : 0;
             e.range = bin[k] ? r1 : r0;
             if (e.range < (uint64_t(1) << 51)) {                 // min_range, arithmetic_code.h:61-62,115
                 if (e.range == 0) { st = AVR_SLICE_ZERO_PROB; dead = true; }           // :116-118 (range stays 0 from here on: 0 / total * pos,
                                                                                      // nothing more is emitted; the chunk loop below ends the walk)
-                else if (VARIANT & 2) do { e.range <<= 8; e.w.n++; } while (e.range < (uint64_t(1) << 55));
                 else do e.emit_digit(); while (e.range < (uint64_t(1) << 55));         // :120-122
             }
         }
@@ -415,11 +401,8 @@ __global__ __launch_bounds__(64) void k_range_encode(
         nx1 = nx2;
     }
     if (active) {
-        if (VARIANT & 2) e.w.n = uint32_t(e.range >> 40);
-        else {
-            if (st == AVR_SLICE_OK) e.finish();                  // recode.cpp:1100
-            e.w.flush();
-        }
+        if (st == AVR_SLICE_OK) e.finish();                      // recode.cpp:1100
+        e.w.flush();
         if (st == AVR_SLICE_OK && e.w.n > cap) st = AVR_SLICE_OVERFLOW;
     }
     out_len[slice] = active ? e.w.n : 0;
@@ -628,6 +611,25 @@ __global__ __launch_bounds__(64) void k_synth_slices(
 
 // ------------------------------------------------------------------ launchers
 
+// The renumbering's scratch (4.25 KiB: used[32] + n_dense | table[1024] | index[1024]): one per (device, stream), made on
+// first use and kept -- work on one stream is ordered, so consecutive calls may share it, and no call allocates.
+static hipError_t stream_scratch(hipStream_t s, uint8_t **out) {
+    struct Slot { int dev; hipStream_t s; uint8_t *p; };
+    static std::vector<Slot> slots;
+    static std::mutex mu;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Slot &x : slots)
+        if (x.dev == dev && x.s == s) { *out = x.p; return hipSuccess; }
+    uint8_t *p = nullptr;
+    if ((e = hipMalloc(reinterpret_cast<void **>(&p), 256 + 4096)) != hipSuccess) return e;
+    slots.push_back(Slot{dev, s, p});
+    *out = p;
+    return hipSuccess;
+}
+
 // The one-lane-per-slice kernel keeps 64 x (contexts) state bytes in LDS per wave, so it renumbers the batch onto the
 // contexts its records use (census -> k_k1p_densemap -> one 4-byte read-back to size the launch), applied to the
 // records as they are loaded (sel_off): nothing is rewritten, init_states / final_states stay in the caller's numbering.
@@ -643,14 +645,13 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
     uint8_t *scratch = nullptr;                                  // used[32] + n_dense | table[1024] | index[1024]
     const uint16_t *table = nullptr, *index = nullptr;
     bool retry = false;                                          // the census was a sample: a second launch takes what it missed
-    if (dense && want_status == AVR_SLICE_OK && n_states > 8 && !getenv("AVR_NO_DENSE")) {
-        if ((err = hipMallocAsync(reinterpret_cast<void **>(&scratch), 256 + 4096, s)) != hipSuccess) return err;
+    if (dense && want_status == AVR_SLICE_OK && n_states > 8 && !no_dense()) {
+        if ((err = stream_scratch(s, &scratch)) != hipSuccess) return err;
         uint32_t *used = reinterpret_cast<uint32_t *>(scratch);
         uint16_t *t = reinterpret_cast<uint16_t *>(scratch + 256);
         if ((err = hipMemsetAsync(used, 0, 256, s)) != hipSuccess) return err;
         const dim3 cgrid(((n_slices + 63) / 64 + kCensusTiles - 1) / kCensusTiles);
-        const char *cs = getenv("AVR_CENSUS_STRIDE");
-        const uint32_t stride = cs && atoi(cs) > 0 ? uint32_t(atoi(cs)) : kCensusStride;
+        const uint32_t stride = test_hooks().census_stride ? test_hooks().census_stride : kCensusStride;
         retry = stride > 1;
         if (tiled) hipLaunchKernelGGL(k_k1_census<true>, cgrid, dim3(256), 0, s, recs, off, n_bins, order, n_slices, used, stride);
         else hipLaunchKernelGGL(k_k1_census<false>, cgrid, dim3(256), 0, s, recs, off, n_bins, order, n_slices, used, stride);
@@ -678,11 +679,10 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
         const uint32_t waves = per_wave * kK1Waves <= 60 * 1024 ? kK1Waves : per_wave * 2 <= 60 * 1024 ? 2 : 1;
         const uint32_t lds = waves * per_wave;
         const dim3 grid((n_slices + 64 * waves - 1) / (64 * waves)), block(64 * waves);
-        // AVR_K1_FORM=norm: the coder in normalised form with the digits taken every fourth bin, in step across the wave
+        // test hook k1_form_norm: the coder in normalised form with the digits taken every fourth bin, in step across the wave
         // (CabacLaneN).  Same bytes; measured on config 5 at the same 2.63 ms per step as the reference's form (what its
         // emit branch costs, the 64-bit low of the other form costs again), so the form that reads like cabac_code.h stays.
-        const char *form = getenv("AVR_K1_FORM");
-        const bool norm = form && strcmp(form, "norm") == 0;
+        const bool norm = test_hooks().k1_form_norm != 0;
         auto kern = tiled ? (norm ? k_cabac_encode<true, true> : k_cabac_encode<true, false>)
                           : (norm ? k_cabac_encode<false, true> : k_cabac_encode<false, false>);
         if (lds > 48 * 1024) {
@@ -695,7 +695,6 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
     };
     err = launch(n_rows, table, index, want_status);
     if (err == hipSuccess && retry) err = launch(n_states, nullptr, nullptr, AVR_SLICE_RETRY_SERIAL);
-    if (scratch) { const hipError_t e2 = hipFreeAsync(scratch, s); if (err == hipSuccess) err = e2; }
     return err;
 }
 
@@ -705,15 +704,8 @@ hipError_t launch_range_encode(bool tiled, hipStream_t s, const void *recs, cons
                                int32_t *status) {
     if (n_slices == 0) return hipSuccess;
     const dim3 grid((n_slices + 63) / 64), block(64);
-    const char *v = getenv("AVR_K2_VARIANT");
-    const int variant = v ? atoi(v) : 0;
-#define AVR_K2_LAUNCH(T, V) hipLaunchKernelGGL((k_range_encode<T, V>), grid, block, 0, s, recs, off, n_bins, order, n_slices, out, out_off, out_len, status)
-    if (!tiled) AVR_K2_LAUNCH(false, 0);
-    else if (variant == 1) AVR_K2_LAUNCH(true, 1);
-    else if (variant == 2) AVR_K2_LAUNCH(true, 2);
-    else if (variant == 3) AVR_K2_LAUNCH(true, 3);
-    else AVR_K2_LAUNCH(true, 0);
-#undef AVR_K2_LAUNCH
+    if (tiled) hipLaunchKernelGGL(k_range_encode<true>, grid, block, 0, s, recs, off, n_bins, order, n_slices, out, out_off, out_len, status);
+    else hipLaunchKernelGGL(k_range_encode<false>, grid, block, 0, s, recs, off, n_bins, order, n_slices, out, out_off, out_len, status);
     return hipGetLastError();
 }
 

@@ -40,10 +40,17 @@ class bit_reader {                                       // RBSP bits, MSB first
         for (int i = 0; i < bits; i++) v = (v << 1) | bit();
         return v;
     }
-    uint32_t ue() {                                      // 9.1
+    uint32_t ue() {                                      // 9.1; codes of 32 or more leading zeros do not fit 32 bits
         int zeros = 0;
-        while (bit() == 0) if (++zeros > 32) throw bad_stream("Exp-Golomb code too long");
+        while (bit() == 0) if (++zeros > 31) throw bad_stream("Exp-Golomb code too long");
         return zeros ? ((1u << zeros) - 1u) + u(zeros) : 0u;
+    }
+    // ue(v) of a syntax element with a range: everything the parser turns into an int, an index or a size goes through here
+    // (the reference leaves this to libavcodec, which checks every one of them)
+    int ue_max(uint32_t max, const char *what) {
+        const uint32_t v = ue();
+        if (v > max) throw bad_stream(std::string(what) + " out of range");
+        return int(v);
     }
     int32_t se() { const uint32_t k = ue(); return (k & 1u) ? int32_t((k + 1) / 2) : -int32_t(k / 2); }
     bool more_rbsp_data() const {                        // 7.2: anything before the last 1 bit
@@ -98,6 +105,9 @@ inline void skip_scaling_list(bit_reader &r, int size) {             // 7.3.2.1.
     }
 }
 
+// Level 6.2 allows 139 264 macroblocks a frame and 16 384 samples a side (Table A-1); twice that is this parser's limit.
+constexpr int kMaxPicMbsSide = 2048, kMaxPicMbs = 1 << 18;
+
 inline void parse_sps(const std::vector<uint8_t> &rbsp, sps_t sps[32]) {     // 7.3.2.1.1 (after the NAL header byte)
     bit_reader r(rbsp.data(), rbsp.size());
     sps_t s;
@@ -109,19 +119,18 @@ inline void parse_sps(const std::vector<uint8_t> &rbsp, sps_t sps[32]) {     // 
     const int p = s.profile_idc;
     if (p == 100 || p == 110 || p == 122 || p == 244 || p == 44 || p == 83 || p == 86 || p == 118 || p == 128 || p == 138 || p == 139 ||
         p == 134 || p == 135) {
-        s.chroma_format_idc = int(r.ue());
-        if (s.chroma_format_idc > 3) throw bad_stream("chroma_format_idc out of range");
+        s.chroma_format_idc = r.ue_max(3, "chroma_format_idc");
         if (s.chroma_format_idc == 3) s.separate_colour_plane = int(r.u(1));
-        s.bit_depth_luma = 8 + int(r.ue());
-        s.bit_depth_chroma = 8 + int(r.ue());
+        s.bit_depth_luma = 8 + r.ue_max(6, "bit_depth_luma_minus8");
+        s.bit_depth_chroma = 8 + r.ue_max(6, "bit_depth_chroma_minus8");
         r.u(1);                                          // qpprime_y_zero_transform_bypass_flag
         if (r.u(1))                                      // seq_scaling_matrix_present_flag
             for (int i = 0; i < (s.chroma_format_idc != 3 ? 8 : 12); i++)
                 if (r.u(1)) skip_scaling_list(r, i < 6 ? 16 : 64);
     }
-    s.log2_max_frame_num = 4 + int(r.ue());
-    s.poc_type = int(r.ue());
-    if (s.poc_type == 0) s.log2_max_poc_lsb = 4 + int(r.ue());
+    s.log2_max_frame_num = 4 + r.ue_max(12, "log2_max_frame_num_minus4");
+    s.poc_type = r.ue_max(2, "pic_order_cnt_type");
+    if (s.poc_type == 0) s.log2_max_poc_lsb = 4 + r.ue_max(12, "log2_max_pic_order_cnt_lsb_minus4");
     else if (s.poc_type == 1) {
         s.delta_pic_order_always_zero = int(r.u(1));
         r.se();
@@ -132,8 +141,9 @@ inline void parse_sps(const std::vector<uint8_t> &rbsp, sps_t sps[32]) {     // 
     }
     r.ue();                                              // max_num_ref_frames
     r.u(1);                                              // gaps_in_frame_num_value_allowed_flag
-    s.width_mbs = 1 + int(r.ue());
-    s.height_map_units = 1 + int(r.ue());
+    s.width_mbs = 1 + r.ue_max(kMaxPicMbsSide - 1, "pic_width_in_mbs_minus1");
+    s.height_map_units = 1 + r.ue_max(kMaxPicMbsSide - 1, "pic_height_in_map_units_minus1");
+    if (int64_t(s.width_mbs) * s.height_map_units > kMaxPicMbs) throw bad_stream("picture size out of range");
     s.frame_mbs_only = int(r.u(1));
     if (!s.frame_mbs_only) s.mbaff = int(r.u(1));
     s.direct_8x8_inference = int(r.u(1));
@@ -146,17 +156,17 @@ inline void parse_pps(const std::vector<uint8_t> &rbsp, pps_t pps[256]) {    // 
     pps_t p;
     const uint32_t id = r.ue();
     if (id > 255) throw bad_stream("pic_parameter_set_id out of range");
-    p.sps_id = int(r.ue());
-    if (p.sps_id > 31) throw bad_stream("seq_parameter_set_id out of range");
+    p.sps_id = r.ue_max(31, "seq_parameter_set_id");
     p.cabac = int(r.u(1));
     p.bottom_field_pic_order_present = int(r.u(1));
-    p.slice_groups = 1 + int(r.ue());
+    p.slice_groups = 1 + r.ue_max(7, "num_slice_groups_minus1");
     if (p.slice_groups == 1) {                           // with slice groups the rest is not needed: such slices are not hooked
-        p.refs_l0 = 1 + int(r.ue());
-        p.refs_l1 = 1 + int(r.ue());
+        p.refs_l0 = 1 + r.ue_max(31, "num_ref_idx_l0_default_active_minus1");
+        p.refs_l1 = 1 + r.ue_max(31, "num_ref_idx_l1_default_active_minus1");
         p.weighted_pred = int(r.u(1));
         p.weighted_bipred_idc = int(r.u(2));
         p.pic_init_qp = 26 + r.se();
+        if (p.pic_init_qp < -36 || p.pic_init_qp > 51) throw bad_stream("pic_init_qp_minus26 out of range");
         r.se();                                          // pic_init_qs_minus26
         r.se();                                          // chroma_qp_index_offset
         p.deblocking_control_present = int(r.u(1));
@@ -186,7 +196,7 @@ inline slice_header parse_slice_header(const std::vector<uint8_t> &rbsp, int nal
                                        const pps_t pps_tab[256]) {
     bit_reader r(rbsp.data(), rbsp.size());
     slice_header h;
-    h.first_mb = int(r.ue());
+    h.first_mb = r.ue_max(uint32_t(kMaxPicMbs) - 1, "first_mb_in_slice");
     const uint32_t st = r.ue();
     if (st > 9) throw bad_stream("slice_type out of range");
     h.type = int(st % 5);
@@ -215,8 +225,8 @@ inline slice_header parse_slice_header(const std::vector<uint8_t> &rbsp, int nal
     h.refs[1] = pps.refs_l1;
     if (h.type != SLICE_I) {
         if (r.u(1)) {                                    // num_ref_idx_active_override_flag
-            h.refs[0] = 1 + int(r.ue());
-            if (h.type == SLICE_B) h.refs[1] = 1 + int(r.ue());
+            h.refs[0] = 1 + r.ue_max(31, "num_ref_idx_l0_active_minus1");
+            if (h.type == SLICE_B) h.refs[1] = 1 + r.ue_max(31, "num_ref_idx_l1_active_minus1");
         }
         if (h.refs[0] > 32 || h.refs[1] > 32) throw bad_stream("num_ref_idx_active out of range");
         for (int list = 0; list < (h.type == SLICE_B ? 2 : 1); list++)      // ref_pic_list_modification(), 7.3.3.1
@@ -250,9 +260,9 @@ inline slice_header parse_slice_header(const std::vector<uint8_t> &rbsp, int nal
                 if (op == 4) r.ue();
             }
     }
-    if (h.type != SLICE_I) h.cabac_init_idc = int(r.ue());
-    if (h.cabac_init_idc > 2) throw bad_stream("cabac_init_idc out of range");
+    if (h.type != SLICE_I) h.cabac_init_idc = r.ue_max(2, "cabac_init_idc");
     h.qp = pps.pic_init_qp + r.se();
+    if (h.qp < -36 || h.qp > 51) throw bad_stream("slice_qp_delta out of range");
     if (pps.deblocking_control_present && r.ue() != 1) { r.se(); r.se(); }
     r.align();                                           // cabac_alignment_one_bit
     h.data_offset = r.pos() / 8;
@@ -262,7 +272,7 @@ inline slice_header parse_slice_header(const std::vector<uint8_t> &rbsp, int nal
     h.transform_8x8_mode = pps.transform_8x8_mode;
     h.direct_8x8_inference = sps.direct_8x8_inference;
     if (h.type != SLICE_I && h.cabac_init_idc != 0) throw unsupported("cabac_init_idc 1 / 2 (initialisation columns not reproduced, avr_h264_tables.h)");
-    if (h.first_mb >= h.width_mbs * h.height_mbs) throw bad_stream("first_mb_in_slice outside the picture");
+    if (int64_t(h.first_mb) >= int64_t(h.width_mbs) * h.height_mbs) throw bad_stream("first_mb_in_slice outside the picture");
     return h;
 }
 
@@ -323,7 +333,7 @@ class slice_parser {
         int addr = h_.first_mb, count = 0;
         prev_qp_delta_nonzero_ = false;
         for (;;) {
-            if (addr >= total) throw bad_stream("macroblock address past the end of the picture");
+            if (addr < 0 || addr >= total || size_t(addr) >= mbs_.size()) throw bad_stream("macroblock address past the end of the picture");
             mb_x_ = addr % h_.width_mbs;
             mb_y_ = addr / h_.width_mbs;
             cur_ = &mbs_[size_t(addr)];

@@ -54,3 +54,18 @@ def avr():
     import avrecode_ms_amd
     avrecode_ms_amd.lib()
     return avrecode_ms_amd
+
+
+@pytest.fixture
+def hooks(avr):
+    """hooks(name=value, ...): for the rest of the test, avr.lib() is the -DAVR_TEST_HOOKS build of the library
+    (libavrecode_hip_hooks.so) with these hooks set; the product library has no such switches.  A second call replaces
+    the first one's settings."""
+    import contextlib
+    stack = contextlib.ExitStack()
+
+    def set_hooks(**kw):
+        stack.close()
+        stack.enter_context(avr.test_hooks(**kw))
+    yield set_hooks
+    stack.close()

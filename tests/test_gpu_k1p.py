@@ -144,14 +144,14 @@ def test_chunked_full_size_config2_sampled(avr, oracle):
     assert w.results()[0] == again == got
 
 
-def test_batch_api_takes_the_chunked_path_for_long_slices(avr, oracle, monkeypatch):
+def test_batch_api_takes_the_chunked_path_for_long_slices(avr, oracle, hooks):
     rng = np.random.default_rng(77)
     slices = [oracle_lib.random_cabac_stream(rng, int(rng.integers(15000, 40000)), 200) for _ in range(12)]
     slices.append((np.array([0 | (300 << 1), 1 | (1025 << 1)], dtype=np.uint16), np.zeros(200, np.uint8)))   # bad selector
     want = [oracle.cabac_encode(r, s) for r, s in slices]
     for force in (None, "serial", "chunked"):
         if force:
-            monkeypatch.setenv("AVR_K1_PATH", force)
+            hooks(k1_path={"serial": 1, "chunked": 2}[force])
         with avr.Batch(0, len(slices), sum(len(r) for r, _ in slices) + 8) as b:
             for r, s in slices:
                 b.add_slice_cabac(r, s)
@@ -258,12 +258,12 @@ def test_serial_codes_kernel_equals_stage2_and_oracle(avr, oracle):
 
 
 @pytest.mark.parametrize("every", [1, 3])
-def test_phase_d_hand_over_is_coded_by_the_serial_kernels(avr, oracle, monkeypatch, every):
+def test_phase_d_hand_over_is_coded_by_the_serial_kernels(avr, oracle, hooks, every):
     """Phase D hands a slice whose carries it does not resolve in parallel to a serial kernel.  The pattern (a
-    carry >= 2 into a 33-digit segment ffff...fffe) does not occur in practice, so the test switch
-    AVR_K1P_FORCE_RETRY makes phase D hand over every n-th slice: the bytes must still be the oracle's, from
+    carry >= 2 into a 33-digit segment ffff...fffe) does not occur in practice, so the test hook
+    k1p_force_retry_every (test build of the library only) makes phase D hand over every n-th slice: the bytes must still be the oracle's, from
     records (k_cabac_encode) and from resolved codes (k_cabac_encode_codes), with status 0 everywhere."""
-    monkeypatch.setenv("AVR_K1P_FORCE_RETRY", str(every))
+    hooks(k1p_force_retry_every=every)
     rng = np.random.default_rng(31 + every)
     slices = [oracle_lib.random_cabac_stream(rng, int(rng.integers(1, 30000)), 120, terminate=bool(i % 3)) for i in range(20)]
     want = [oracle.cabac_encode(r, s) for r, s in slices]
@@ -277,7 +277,7 @@ def test_phase_d_hand_over_is_coded_by_the_serial_kernels(avr, oracle, monkeypat
     got, status = w.results()
     assert not any(status) and got == [x[0] for x in want]
     # and through the batch API (what the host decompressor uses)
-    monkeypatch.setenv("AVR_K1_PATH", "chunked")
+    hooks(k1p_force_retry_every=every, k1_path=2)
     with avr.Batch(0, len(slices), sum(len(r) for r, _ in slices) + 64) as b:
         for r, s in slices:
             b.add_codes(_codes_of(avr, r, s))
@@ -329,14 +329,14 @@ def test_chunked_full_size_configs_3_and_4_sampled(avr, oracle, workload, n_slic
     assert 0.9 < w.total_bins / (8 * sum(lens)) < 1.8
 
 
-@pytest.mark.parametrize("stride", ["1", "16", "4099"])
-def test_chunked_census_sample_second_pass_and_validation(avr, oracle, stride, monkeypatch):
+@pytest.mark.parametrize("stride", [1, 16, 4099])
+def test_chunked_census_sample_second_pass_and_validation(avr, oracle, stride, hooks):
     """The intra-slice parallel path renumbers the batch's contexts from a sample of the records; the chunk sort, which
     looks every record up, sets aside the slices with a bin in a context the sample missed, and those take a second
     pass with every record counted (stride 4099: the sample is next to nothing, so every slice with a context bin does;
     stride 1: no sampling).  The same kernel is where records are validated now: a selector the slice does not have, a
     record with a bit above its selector, put_terminate(1) anywhere but last -- each in the middle of a long slice."""
-    monkeypatch.setenv("AVR_CENSUS_STRIDE", stride)
+    hooks(census_stride=stride)
     rng = np.random.default_rng(91)
     ns = 300
     slices = []

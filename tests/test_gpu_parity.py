@@ -71,10 +71,11 @@ def test_range_golden_vectors(avr):
 
 @pytest.mark.parametrize("form", ["ref", "norm"])
 @pytest.mark.parametrize("n_states", [4, 64, 460, 1024])
-def test_cabac_random_ragged(avr, oracle, n_states, form, monkeypatch):
+def test_cabac_random_ragged(avr, oracle, n_states, form, hooks):
     """form: the one-lane-per-slice coder as the reference writes it (shipped), and in normalised form with the digits
-    taken every fourth bin in step across the wave (AVR_K1_FORM=norm, kept as a measured variant)."""
-    monkeypatch.setenv("AVR_K1_FORM", form)
+    taken every fourth bin in step across the wave (test hook k1_form_norm: a measured variant, in the test build only)."""
+    if form == "norm":
+        hooks(k1_form_norm=1)
     rng = np.random.default_rng(100 + n_states)
     slices = []
     for i in range(200):                          # 3+ tiles, lengths from 0 to a few thousand
@@ -87,15 +88,14 @@ def test_cabac_random_ragged(avr, oracle, n_states, form, monkeypatch):
         assert got == oracle.cabac_encode(recs, st), f"slice {i} n={len(recs)}"
 
 
-@pytest.mark.parametrize("stride", ["1", "16", "1000003"])
-def test_cabac_census_sample_and_hand_back(avr, oracle, stride, monkeypatch):
+@pytest.mark.parametrize("stride", [1, 16, 1000003])
+def test_cabac_census_sample_and_hand_back(avr, oracle, stride, hooks):
     """The one-lane-per-slice kernel renumbers the batch's contexts from a SAMPLE of the records (every 16th chunk); a
     slice with a bin in a context the sample missed comes back from the first launch as 'retry' and is coded by the
     second, unrenumbered one.  Same bytes, final states and statuses whatever the sample saw: the full census (1), the
     shipped stride (16: the 1024-context streams here have many contexts that occur once or twice, so a good part of
     the slices takes the second launch), and a stride that samples next to nothing (every slice handed back)."""
-    monkeypatch.setenv("AVR_CENSUS_STRIDE", stride)
-    monkeypatch.setenv("AVR_K1_PATH", "serial")
+    hooks(census_stride=stride, k1_path=1)
     rng = np.random.default_rng(77)
     slices = []
     for i in range(300):

@@ -50,6 +50,7 @@ def test_chunked_range_coder_equals_the_oracle(emul, oracle, chunk):
         want, status = oracle.range_encode(recs)
         got, info = emul_encode(emul, recs, chunk)
         assert status == 0 and got == want, f"stream {k} n={n} chunk={chunk} info={info}"
+        assert info[3] == n                                  # the double-precision pass 1 walked every bin
 
 
 def test_chunked_range_coder_extremes(emul, oracle):
@@ -70,6 +71,31 @@ def test_chunked_range_coder_extremes(emul, oracle):
             want, status = oracle.range_encode(recs)
             got, info = emul_encode(emul, recs, chunk)
             assert status == 0 and got == want, f"case {k} chunk={chunk} info={info}"
+
+
+def test_double_precision_range_recurrence_is_exact(emul):
+    """Pass 1's double-precision form (range_step_fp, csrc/avr_k2p.h) against the 64-bit integer form over millions of bins:
+    every (pos, neg) pair from 1 to 127 -- beyond what the estimator update of recode.cpp:1037-1052 can reach -- in random
+    order, runs of the most lopsided pairs, and the adaptive streams; then records with pos or neg 0, which it must hand over."""
+    emul.k2p_emul_fp_walk.restype = ctypes.c_size_t
+    def walk(recs):
+        recs = np.ascontiguousarray(recs, np.uint16)
+        return emul.k2p_emul_fp_walk(recs.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(recs.size)), recs.size
+    rng = np.random.default_rng(7)
+    n = 4_000_000
+    pos, neg = rng.integers(1, 128, n), rng.integers(1, 128, n)
+    for p1 in (0.5, 0.02, 0.98):
+        got, size = walk((rng.random(n) < p1).astype(np.uint16) | (pos << 1) | (neg << 8))
+        assert got == size
+    lop = np.where(rng.random(n) < 0.5, 1 | (1 << 1) | (127 << 8), 0 | (127 << 1) | (1 << 8)).astype(np.uint16)     # 7 bits a bin
+    assert walk(lop)[0] == n
+    for k in range(20):
+        recs = oracle_lib.random_range_stream(rng, 50_000, adaptive=True)
+        assert walk(recs)[0] == recs.size
+    # neg = 0 and bin 0: the new range is range mod pos, below 2^7 -- not this form's business
+    odd = np.array([0 | (3 << 1) | (4 << 8)] * 40 + [0 | (9 << 1) | (0 << 8)] + [1 | (3 << 1) | (4 << 8)] * 40, np.uint16)
+    got, size = walk(odd)
+    assert got == size + 1 + 40
 
 
 def test_zero_probability_bin_is_reported(emul, oracle):
