@@ -729,6 +729,7 @@ int avr_multi_run(avr_multi *m) {
     std::vector<int> rc(nd, AVR_OK);
     std::vector<std::string> err(nd);
     auto work = [&](size_t d) {
+        if (m->sub[d]) { avr_batch_destroy(m->sub[d]); m->sub[d] = nullptr; }    // a run that failed on another device left this one behind
         if (mine[d].empty()) return;
         avr_batch *b = avr_batch_create(m->devices[d], mine[d].size(), size_t(m->load[d]) + 8);
         if (!b) { rc[d] = AVR_ERR_HIP; err[d] = avr_last_error(); return; }

@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 DEFAULT_SLICES = {2: 512, 3: 4096, 4: 16384, 5: 1 << 20}
+K1P_KERNELS = ("K1p: k_k1p_{census,densemap,local,ctxchain,replay,b2,c,d} + the idle serial fallback (one step = all of "
+               "them; largest: k_k1p_replay)")
 WORKLOAD_NAME = {
     2: "config2: 1080p30 CABAC clip, 1 slice/frame, 512 frames (synthetic, 8160 macroblocks per slice)",
     3: "config3: 16 files x 256 slices, log-normal slice sizes (synthetic)",
@@ -35,109 +37,197 @@ WORKLOAD_NAME = {
 }
 
 
-def cpu_baseline(avr, workload, kind, n_slices, first_slice, gpu_bytes_of, budget_s=20.0):
-    """Time the CPU checker on a bounded sample and byte-compare the GPU output with it."""
+def socket0_cpus():
+    """The CPUs of one socket (the lowest `physical id` of /proc/cpuinfo) among those this process may run on."""
+    allowed = sorted(os.sched_getaffinity(0))
+    try:
+        sock, cur = {}, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cur = int(line.split(":")[1])
+            elif line.startswith("physical id") and cur is not None:
+                sock[cur] = int(line.split(":")[1])
+        ids = sorted({sock[c] for c in allowed if c in sock})
+        if ids:
+            return [c for c in allowed if sock.get(c) == ids[0]], len(ids)
+    except (OSError, ValueError):
+        pass
+    return allowed, 1
+
+
+def host_sample(avr, workload, kind, n_slices, first_slice, max_bins):
+    """The first m slices of the workload generated on the host: (m, n_bins, compact records of `kind`, offsets, init states, cfg)."""
     import ctypes
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib
-    oracle = oracle_lib.load_oracle()
-    ref = oracle_lib.load_ref() if kind == avr.KIND_CABAC else None
-    cores = max(1, len(os.sched_getaffinity(0)))
     L = avr.lib()
     cfg = avr.synth_config(workload, 1000, first_slice)
     nb_all = np.zeros(n_slices, dtype=np.uint32)
     L.avr_synth_count_host(ctypes.byref(cfg), kind, n_slices, nb_all.ctypes.data)
-    # bounded sample: as many leading slices as ~budget_s of CPU work allows at ~40 Mbin/s/core
-    max_bins = int(budget_s * 40e6 * cores)
     cum = np.cumsum(nb_all.astype(np.int64))
     m = int(min(n_slices, max(1, np.searchsorted(cum, max_bins))))
     nb = nb_all[:m]
     off = np.zeros(m + 1, dtype=np.uint64)
     off[1:] = np.cumsum((nb.astype(np.uint64) + 7) // 8 * 8)
-    recs = np.zeros(int(off[-1]), dtype=np.uint16)
-    states = np.zeros(m * cfg.n_states, dtype=np.uint8)
-    L.avr_synth_generate_host(ctypes.byref(cfg), kind, m, off.ctypes.data, recs.ctypes.data, states.ctypes.data)
+
+    def gen(k):
+        recs = np.zeros(int(off[-1]), dtype=np.uint16)
+        states = np.zeros(m * cfg.n_states, dtype=np.uint8)
+        L.avr_synth_generate_host(ctypes.byref(cfg), k, m, off.ctypes.data, recs.ctypes.data, states.ctypes.data)
+        # compact copy without the padding, so that off[i+1] - off[i] is the slice length
+        parts = [recs[int(off[i]):int(off[i]) + int(nb[i])] for i in range(m)]
+        return (np.concatenate(parts) if parts else np.zeros(0, np.uint16)), states
+    roff = np.zeros(m + 1, dtype=np.uint64)
+    roff[1:] = np.cumsum(nb.astype(np.uint64))
+    return m, nb, gen, roff, cfg
+
+
+def cpu_baseline(avr, workload, kind, n_slices, first_slice, gpu_bytes_of, budget_s=20.0):
+    """Time the CPU checker on a bounded sample, on the cores of ONE socket, and byte-compare the GPU output with it.
+
+    kind "reference" (oracle/_ref, built from the reference's own arithmetic_code.h): K1 = ref_cabac_encode, the reference
+    coder under the restated CABAC layer; K2 = ref_model_range_encode, the reference coder driven the way recode.cpp drives
+    it -- std::function probability over a std::map<tuple<const void*, int, int>, estimator> (recode.cpp:823-827, 1037-1052).
+    The build's own C restatement (oracle/, "port") is timed beside it."""
+    import ctypes
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle = oracle_lib.load_oracle()
+    ref = oracle_lib.load_ref()
+    P = oracle_lib.ptr
+    all_cpus = sorted(os.sched_getaffinity(0))
+    cpus, sockets = socket0_cpus()
+    cores = len(cpus)
+    rate = 40e6 if kind == avr.KIND_CABAC else 15e6         # rough bins/s per thread of the reference-kind coder
+    m, nb, gen, roff, cfg = host_sample(avr, workload, kind, n_slices, first_slice, int(budget_s * rate * cores))
+    recs, states = gen(kind)                                 # what the GPU codes
+    keyed = gen(avr.KIND_CABAC)[0] if kind == avr.KIND_RANGE else recs   # (bin, selector): the reference model's input
     out_off = np.zeros(m + 1, dtype=np.uint64)
     out_off[1:] = np.cumsum(nb.astype(np.uint64) + 16)
     out = np.zeros(int(out_off[-1]), dtype=np.uint8)
     out_len = np.zeros(m, dtype=np.uint32)
     status = np.zeros(m, dtype=np.int32)
-    P = oracle_lib.ptr
-    # slice-exact offsets for the checker (records are padded to 8 per slice in `recs`)
-    roff = off.copy()
+    is_cabac = kind == avr.KIND_CABAC
 
-    def run_port(threads):
-        # the oracle batch helper wants [off[i], off[i+1]) == the slice: call per contiguous run
+    def run_port(threads, count=m):
         rc = oracle.L.avr_oracle_encode_batch(
-            ctypes.c_int(kind), P(recs_c), P(roff_c), ctypes.c_size_t(m), P(states if kind == avr.KIND_CABAC else None),
-            ctypes.c_size_t(cfg.n_states if kind == avr.KIND_CABAC else 0), P(out), P(out_off), P(out_len), P(status),
-            ctypes.c_int(threads))
+            ctypes.c_int(kind), P(recs), P(roff), ctypes.c_size_t(count), P(states if is_cabac else None),
+            ctypes.c_size_t(cfg.n_states if is_cabac else 0), P(out), P(out_off), P(out_len), P(status), ctypes.c_int(threads))
         assert rc == 0
 
-    # compact copy without padding so that off[i+1]-off[i] is the slice length
-    parts = [recs[int(off[i]):int(off[i]) + int(nb[i])] for i in range(m)]
-    recs_c = np.concatenate(parts) if parts else np.zeros(0, np.uint16)
-    roff_c = np.zeros(m + 1, dtype=np.uint64)
-    roff_c[1:] = np.cumsum(nb.astype(np.uint64))
+    def ref_range(lo, hi):
+        if hi <= lo:
+            return
+        at = lambda a, k, w: ctypes.c_void_p(a.ctypes.data + w * k)
+        if is_cabac:
+            ref.L.ref_cabac_encode_batch(P(keyed), at(roff, lo, 8), ctypes.c_size_t(hi - lo), at(states, lo * cfg.n_states, 1),
+                                         ctypes.c_size_t(cfg.n_states), P(out), at(out_off, lo, 8), at(out_len, lo, 4))
+        else:
+            ref.L.ref_model_range_encode_batch(P(keyed), at(roff, lo, 8), ctypes.c_size_t(hi - lo), P(out), at(out_off, lo, 8),
+                                               at(out_len, lo, 4))
 
-    def run_ref(threads):
-        from concurrent.futures import ThreadPoolExecutor
-        bounds = np.linspace(0, m, threads * 4 + 1).astype(int)
+    def run_ref(threads, count=m):
+        bounds = np.linspace(0, count, threads * 4 + 1).astype(int)
+        with ThreadPoolExecutor(threads) as ex:              # ctypes calls release the GIL
+            list(ex.map(lambda k: ref_range(int(bounds[k]), int(bounds[k + 1])), range(threads * 4)))
 
-        def work(k):
-            lo, hi = int(bounds[k]), int(bounds[k + 1])
-            if hi > lo:
-                ref.L.ref_cabac_encode_batch(
-                    P(recs_c), ctypes.c_void_p(roff_c.ctypes.data + 8 * lo), ctypes.c_size_t(hi - lo),
-                    ctypes.c_void_p(states.ctypes.data + lo * cfg.n_states), ctypes.c_size_t(cfg.n_states),
-                    P(out), ctypes.c_void_p(out_off.ctypes.data + 8 * lo), ctypes.c_void_p(out_len.ctypes.data + 4 * lo))
-        with ThreadPoolExecutor(threads) as ex:
-            list(ex.map(work, range(threads * 4)))
+    def best_of(runner, threads):
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            runner(threads)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            if dt > budget_s / 2:
+                break
+        return best
 
-    kind_name, runner = ("reference", run_ref) if ref is not None else ("port", run_port)
-    best = None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        runner(cores)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-        if dt > budget_s / 2:
-            break
-    cpu_bytes = [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(m)]
-    total = sum(len(b) for b in cpu_bytes)
-    # single-thread figure (the reference itself is single-threaded, recode.cpp:129) on a smaller cut
-    m1 = max(1, min(m, int(np.searchsorted(np.cumsum(nb.astype(np.int64)), 60e6)) + 1))
-    save = (m,)
-    t0 = time.perf_counter()
-    if ref is not None:
-        ref.L.ref_cabac_encode_batch(P(recs_c), P(roff_c), ctypes.c_size_t(m1), P(states), ctypes.c_size_t(cfg.n_states),
-                                     P(out), P(out_off), P(out_len))
-    else:
-        oracle.L.avr_oracle_encode_batch(ctypes.c_int(kind), P(recs_c), P(roff_c), ctypes.c_size_t(m1),
-                                         P(states if kind == avr.KIND_CABAC else None),
-                                         ctypes.c_size_t(cfg.n_states if kind == avr.KIND_CABAC else 0), P(out), P(out_off),
-                                         P(out_len), P(status), ctypes.c_int(1))
-    dt1 = time.perf_counter() - t0
-    bytes1 = sum(len(b) for b in cpu_bytes[:m1])
-    gpu = gpu_bytes_of(m)
-    parity = "bit-exact" if gpu == cpu_bytes else "MISMATCH"
-    cpu_model, sockets = "unknown", 0
+    def result():
+        return [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(m)]
+
+    res = {}
     try:
-        info = open("/proc/cpuinfo").read()
-        names = [l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("model name")]
+        os.sched_setaffinity(0, cpus)                        # one socket: north_star's "single-socket CPU reference"
+        t_port = best_of(run_port, cores)
+        port_bytes = result()
+        total = sum(len(b) for b in port_bytes)
+        if ref is not None:
+            t_ref = best_of(run_ref, cores)
+            cpu_bytes = result()
+        else:
+            t_ref, cpu_bytes = None, port_bytes
+        # one thread (the reference itself is single-threaded, recode.cpp:129) on a smaller cut
+        m1 = max(1, min(m, int(np.searchsorted(np.cumsum(nb.astype(np.int64)), 30e6)) + 1))
+        bytes1 = sum(len(b) for b in cpu_bytes[:m1])
+        t0 = time.perf_counter()
+        (ref_range(0, m1) if ref is not None else run_port(1, m1))
+        dt1 = time.perf_counter() - t0
+        t_all = None
+        if sockets > 1:                                      # the whole host, for the record
+            os.sched_setaffinity(0, all_cpus)
+            t_all = best_of(run_ref if ref is not None else run_port, len(all_cpus))
+    finally:
+        os.sched_setaffinity(0, all_cpus)
+    gpu = gpu_bytes_of(m)
+    parity = "bit-exact" if gpu == cpu_bytes and gpu == port_bytes else "MISMATCH"
+    cpu_model = "unknown"
+    try:
+        names = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
         cpu_model = names[0] if names else "unknown"
-        sockets = len({l.split(":", 1)[1].strip() for l in info.splitlines() if l.startswith("physical id")}) or 1
     except OSError:
         pass
-    return {
-        "value": total / best, "unit": "bytes/s", "cores": cores, "kind": kind_name,
-        "cpu_model": cpu_model, "sockets": sockets,
+    kind_name, best = ("reference", t_ref) if ref is not None else ("port", t_port)
+    res.update({
+        "value": total / best, "unit": "bytes/s", "cores": cores, "sockets_used": 1, "kind": kind_name,
+        "cpu_model": cpu_model, "sockets_in_host": sockets,
         "sample": f"first {m} of {n_slices} slices of the same workload ({int(nb.astype(np.int64).sum())} bins, "
-                  f"{total} H.264 bytes), best of <=3, one slice per task",
+                  f"{total} H.264 bytes), best of <=3, one slice per task, threads pinned to the {cores} CPUs of socket 0",
+        "port_value": total / t_port,
         "single_thread_value": bytes1 / dt1,
+        "all_sockets_value": (total / t_all) if t_all else None, "all_sockets_cores": len(all_cpus) if t_all else None,
         "parity_vs_gpu": parity, "parity_slices": m,
-    }
+    })
+    return res
+
+
+def e2e_block(avr, workload, kind, n_slices, first_slice, device, rounds=12, objects=3):
+    """PCIe-inclusive rate of the batch API (what test.cpp:52-54 of the reference reports: end-to-end bytes per second): host
+    records in pinned memory in, host bytes out, `objects` avr_batch objects used in turn (submit / wait), so that one
+    batch's H2D runs under another's kernels.  Never `value`: the bench line's value has its inputs resident in HBM."""
+    import numpy as np
+    m, nb, gen, roff, cfg = host_sample(avr, workload, kind, n_slices, first_slice, 80_000_000)
+    m = min(m, 16384)
+    recs, states = gen(kind)
+    total_bins = int(nb[:m].astype(np.int64).sum())
+    bs = [avr.Batch(device, m, total_bins + 8) for _ in range(objects)]
+    try:
+        for b in bs:
+            for i in range(m):
+                r = recs[int(roff[i]):int(roff[i + 1])]
+                if kind == avr.KIND_CABAC:
+                    b.add_slice_cabac(r, states[i * cfg.n_states:(i + 1) * cfg.n_states])
+                else:
+                    b.add_slice_range(r)
+        for b in bs:                                         # first run of an object (it asks the device for the context count)
+            b.submit(); b.wait()
+        out_bytes = sum(len(bs[0].get(i)[0]) for i in range(m))
+        t0 = time.perf_counter()
+        for i in range(rounds):
+            if i >= objects:
+                bs[i % objects].wait()
+            bs[i % objects].submit()
+        for i in range(rounds, rounds + objects):
+            bs[i % objects].wait()
+        t = time.perf_counter() - t0
+        tm = bs[0].timings()
+    finally:
+        for b in bs:
+            b.close()
+    return {"value": rounds * out_bytes / t, "unit": "bytes/s", "ms_per_batch": 1e3 * t / rounds, "slices_per_batch": m,
+            "bins_per_batch": total_bins, "h264_bytes_per_batch": out_bytes, "batch_objects": objects, "rounds": rounds,
+            "input": "uint16 records in pinned host memory (2 B per bin)", "output": "coded bytes in host memory",
+            "h2d_ms_alone": tm["h2d_ms"], "note": "PCIe-inclusive; never the bench line's value"}
 
 
 def main():
@@ -160,6 +250,7 @@ def main():
                     help="weak: every rank codes its own copy of the workload's slice count (default); strong: ONE batch of the "
                          "workload's slice count is split over the ranks (contiguous ranges of near-equal bin totals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive block (host records in, host bytes out)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL; gloo lets several ranks rehearse on one GPU)")
     args = ap.parse_args()
@@ -251,11 +342,14 @@ def main():
         if args.records == "resolved":       # 1 byte per bin in, no state tables
             algo = w.total_bins + out_bytes + 16 * n_slices
         achieved = algo / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per step by PMC: not measured by this run -- the figure of the committed rocprofv3 --pmc passes over this
+        # very command (profiles/pmc_traffic.json, made by tools/collect_profiles.py), or null
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(f"{args.kind}_{path}_w{args.workload}_s{n_slices}", {}).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/pmc_traffic.json" if traffic is not None else None
             except Exception:
                 traffic = None
         line = {
@@ -271,12 +365,12 @@ def main():
                        "n_states": w.n_states, "n_states_declared": declared_states,
                        "layout": "slice-major" if path == "chunked" else "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("K1p: k_k1p_{census,densemap,tn,local,ctxchain,replay,b2,zero,c,d} + the idle serial fallback (one step = "
-                                    "all of them; largest: k_k1p_replay)" if path == "chunked" else
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": (K1P_KERNELS if path == "chunked" else
                                     "k_k1_census (1-in-16 sample) + k_k1p_densemap + k_cabac_encode<tiled> + its hand-back launch (one step = all of them)")
                          if kind == avr.KIND_CABAC else
-                         ("K2p: k_k2p_ranges (the range recurrence, one lane per slice: the wall) + k_k2p_code + k_k2p_finish"
+                         ("K2p: k_k2p_ranges_fp (the range recurrence, one lane per slice: the wall) + its idle hand-over + k_k2p_fits + "
+                          "k_k2p_zero + k_k2p_code + k_k2p_finish"
                           if path == "chunked" else "k_range_encode<tiled>"),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
                          "bins_per_s": w.total_bins / (kernel_ms * 1e-3)},
@@ -288,6 +382,8 @@ def main():
                 return w.results()[0][:m]
             line["cpu_baseline"] = cpu_baseline(avr, args.workload, kind, n_slices, first, gpu_bytes_of)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        if world == 1 and not args.no_e2e and args.records == "bins":
+            line["e2e"] = e2e_block(avr, args.workload, kind, n_slices, first, local_rank)
         print(json.dumps(line), flush=True)
         if status_bad or line.get("cpu_baseline", {}).get("parity_vs_gpu") == "MISMATCH":
             failed = True

@@ -34,6 +34,15 @@
  *       bits 1..7  pos, bits 8..14 neg : the {pos,neg} estimator of the bin's model key at
  *                  the moment it is coded (recode.cpp:823-827, 1064); p(1) = (range/(pos+neg))*pos
  *
+ * Environment.  The library reads three variables, once per process; NONE of them can change a coded byte -- they pick
+ * between mappings that produce the same bytes (tests/ run all of them against the oracle):
+ *   AVR_K1_PATH=serial|chunked   batch API: force one lane per slice / the intra-slice parallel kernels (default: by batch shape)
+ *   AVR_NO_DENSE=1               one-lane-per-slice K1 keeps the caller's context numbering (no renumbering onto the contexts in use)
+ *   AVR_BATCH_NO_HINT=1          avr_batch_submit always asks the device for the batch's context count (and waits for it)
+ * There is no switch that alters output.  The switches tests use to force rare hand-over paths exist only in a separate
+ * build of the same sources with -DAVR_TEST_HOOKS (libavrecode_hip_hooks.so, avr_test_hook_set); this library has neither
+ * the setter nor the code that reads them.
+ *
  * Threading: one avr_batch per host thread; calls on different batches are
  * independent.  Errors: functions return AVR_OK (0) or a negative AVR_ERR_*;
  * avr_last_error() gives the message for the calling thread.  The reference
@@ -171,8 +180,14 @@ int avr_multi_load(avr_multi *m, uint64_t *bins_per_device);
 
 /* ------------------------------------------------------------------ device-resident API
  * All pointers below are DEVICE pointers on `device`; `stream` is a hipStream_t (NULL = the
- * null stream).  Calls only enqueue work.  These are what the batch API is made of and what
- * bench.py times with inputs already resident in HBM.
+ * null stream).  Calls enqueue work on `stream` and return, with ONE exception: the K1 entry points that take
+ * (bin, selector) records -- avr_cabac_encode_tiles_device / _slices_device / _chunked_device and
+ * avr_cabac_resolve_device -- size their launches by the number of contexts the batch uses, which the device counts:
+ * they wait on `stream` once for that 4-byte count (the chunked forms a second time, for the 4-byte count of slices that
+ * need their second pass), i.e. they block the calling thread until the stream has drained up to their census kernel.
+ * A caller that must not block uses the batch API (avr_batch_submit sizes the launches by the previous batch's count and
+ * checks afterwards) or resolved codes (avr_cabac_encode_resolved_device / _codes_device and every K2 entry: no wait).
+ * These are what the batch API is made of and what bench.py times with inputs already resident in HBM.
  *
  * Slice-major layout: slice i's records are recs[rec_off[i] .. rec_off[i] + n_bins[i]);
  * rec_off[] entries are multiples of 8 records (16 bytes).

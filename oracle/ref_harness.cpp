@@ -165,6 +165,22 @@ size_t ref_model_range_encode(const uint8_t *bins, const uint16_t *keys, size_t 
     return copy_out(v, out, cap);
 }
 
+// ---- batch form of ref_model_range_encode for bench.py's cpu_baseline ("reference", compress direction): slices
+// given as CABAC records (bin, selector) -- the selector is the model key, as in the synthetic workloads' own model
+// (one estimator map per slice, started at {1, 1}: csrc/avr_synth.h ModelSink) -- one thread.
+void ref_model_range_encode_batch(const uint16_t *cabac_recs, const uint64_t *off, size_t n_slices,
+                                  uint8_t *out, const uint64_t *out_off, uint32_t *out_len) {
+    std::vector<uint8_t> bins;
+    std::vector<uint16_t> keys;
+    for (size_t i = 0; i < n_slices; i++) {
+        const size_t n = (size_t)(off[i + 1] - off[i]);
+        bins.resize(n);
+        keys.resize(n);
+        for (size_t j = 0; j < n; j++) { bins[j] = cabac_recs[off[i] + j] & 1; keys[j] = cabac_recs[off[i] + j] >> 1; }
+        out_len[i] = (uint32_t)ref_model_range_encode(bins.data(), keys.data(), n, out + out_off[i], (size_t)(out_off[i + 1] - out_off[i]));
+    }
+}
+
 // ---- batch form of ref_cabac_encode, one thread, for bench.py's cpu_baseline ("reference")
 void ref_cabac_encode_batch(const uint16_t *recs, const uint64_t *off, size_t n_slices,
                             const uint8_t *init_states, size_t n_states,

@@ -292,6 +292,27 @@ void t_model_trace(const uint16_t *ctx, const uint8_t *sym, const uint8_t *sig, 
     }
 }
 
+// get_model_key for one setting of the model's position in a block (recode.cpp:683-822): out = the key's three fields;
+// returns -1 when the model rejects the setting (a position outside its table)
+int t_model_key(int coding_type, int cat, int size, int is_dc, int chroma422, int zigzag, int scan8, int num_nonzeros,
+                int observed, int context, int32_t *out) {
+    try {
+        h264_model m;
+        m.update_frame_spec(0, 2, 2);
+        m.mb_coord = CoefficientCoord();
+        m.mb_coord.mb_x = 1; m.mb_coord.mb_y = 1;
+        m.mb_coord.scan8_index = scan8;
+        m.mb_coord.zigzag_index = zigzag;
+        m.sub_mb_cat = cat; m.sub_mb_size = size; m.sub_mb_is_dc = is_dc; m.sub_mb_chroma422 = chroma422;
+        m.frames[m.cur_frame].meta_at(1, 1).num_nonzeros[scan8] = uint8_t(num_nonzeros);
+        m.nonzeros_observed = observed;
+        m.coding_type = CodingType(coding_type);
+        const model_key k = m.get_model_key(context);
+        out[0] = std::get<0>(k); out[1] = std::get<1>(k); out[2] = std::get<2>(k);
+        return 0;
+    } catch (const std::exception &) { return -1; }
+}
+
 // container: parse and re-serialise; returns the length written (0 = parse failure)
 size_t t_container_reserialize(const uint8_t *blob, size_t len, uint8_t *out, size_t cap, uint32_t *n_blocks) {
     Recoded r;

@@ -251,6 +251,46 @@ def test_model_errors(host, oracle):
     assert rc == -1 and b"outside the frame" in err.value
 
 
+def test_model_keys_equal_the_reference_arrays_and_formula(host):
+    """Row a13.  get_model_key over EVERY class of position the reference distinguishes -- block category (14), block size
+    (4x4 / 8x8), DC or not, 4:2:2 chroma DC or not, zig-zag position, the block's nonzero count and how many have been seen
+    -- against keys computed HERE from the reference's own literal arrays (recode.cpp:691-704, lifted as values into
+    tests/golden/model_tables.json by make_model_tables.py) with the formula of recode.cpp:805-807 (significance map) and
+    :815 (end of block).  avr_model.h types those arrays afresh from the standard (inc_8x8_frame, cat_base, min(i / 2, 2)):
+    a wrong entry there would still round-trip, since compress and decompress share the model -- this is what pins it."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_tables.json")))
+    off8x8, cat_lookup, dc422 = g["sig_coeff_flag_offset_8x8"][0], g["cat_lookup"], g["sig_coeff_offset_dc"]
+    assert len(off8x8) == 63 and len(cat_lookup) == 14 and len(dc422) == 7
+    UNKNOWN, UNREACHABLE, RESIDUALS, SIG_MAP, SIG_EOB, SIG_NZ = range(6)     # the order of recode.cpp:685-691 / avr_model.h
+    KEY_SIGNIFICANCE, KEY_EOB = 1026, 1027                                    # stand-ins for &significance_context, &fake_context
+    out = np.zeros(3, np.int32)
+    host.t_model_key.restype = ctypes.c_int
+
+    def key(ct, cat=0, size=16, is_dc=0, c422=0, zz=0, scan8=0, nnz=0, seen=0, ctx=0):
+        rc = host.t_model_key(ct, cat, size, is_dc, c422, zz, scan8, nnz, seen, ctx, P(out))
+        return None if rc else tuple(int(x) for x in out)
+
+    checked = 0
+    for cat in range(14):
+        for size, is_dc, c422 in ((16, 0, 0), (16, 1, 0), (15, 0, 0), (4, 1, 0), (8, 1, 1), (64, 0, 0), (64, 1, 0), (64, 1, 1)):
+            n_pos = 7 if (is_dc and c422) else 63 if size > 32 else min(size, 16)
+            for zz in range(n_pos):
+                zig = dc422[zz] if (is_dc and c422) else off8x8[zz] if size > 32 else zz       # recode.cpp:706-713
+                for scan8, nnz, seen in ((0, 0, 0), (5, 3, 1), (47, 16, 15), (20, 63, 40)):
+                    want = (KEY_SIGNIFICANCE, 64 * nnz + seen, is_dc + 2 * zig + 32 * cat_lookup[cat])   # :805-807
+                    assert key(SIG_MAP, cat, size, is_dc, c422, zz, scan8, nnz, seen, 77) == want, (cat, size, is_dc, c422, zz)
+                    assert key(SIG_EOB, cat, size, is_dc, c422, zz, scan8, nnz, seen, 77) == (KEY_EOB, int(nnz == seen), 0)   # :815
+                    checked += 1
+    assert checked == 14 * (16 + 16 + 15 + 4 + 7 + 63 + 63 + 7) * 4
+    # every other coding type keys on the context alone (:685-690)
+    for ct in (UNKNOWN, UNREACHABLE, RESIDUALS, SIG_NZ):
+        for ctx in (0, 85, 460, 1023, 1024, 1025):
+            assert key(ct, 3, 64, 1, 0, 9, 4, 2, 1, ctx) == (ctx, 0, 0)
+    # positions the reference asserts away (:708, :711, :714) are errors here, not reads past a table
+    assert key(SIG_MAP, 0, 8, 1, 1, 7) is None and key(SIG_MAP, 0, 64, 0, 0, 63) is None and key(SIG_MAP, 14, 16) is None
+
+
 def test_block_neighbours_equal_the_reference_table(host):
     """neighbor_block against the reference's own reverse_scan_8 (recode.cpp:286-319, the table get_neighbor_sub_mb looks
     the left / upper neighbour up in, :426-478), committed as data: tests/golden/reverse_scan8.json."""
