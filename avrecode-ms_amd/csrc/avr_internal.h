@@ -38,6 +38,7 @@ struct TestHooks {
     uint32_t chain_lanes;            // lanes per wave of k_k1p_ctxchain (0 = by batch shape)
     uint32_t k1_form_norm;           // one-lane-per-slice K1 in normalised form (CabacLaneN)
     uint32_t k1_path, no_dense, no_hint;   // the environment switches above, settable per test (non-zero wins over env())
+    uint32_t k2p_seg_len;            // chunks per segment of K2p's overlapped passes (0 = by batch shape): short slices through many segments
 };
 #ifdef AVR_TEST_HOOKS
 TestHooks &test_hooks();

@@ -3,7 +3,8 @@
 //
 //   k_k2p_ranges_fp pass 1  lane per slice       the range recurrence (double-precision form); range and bytes emitted at every chunk start
 //   k_k2p_ranges   pass 1   lane per slice       the same in 64-bit integers: the slices the first form hands over (rare)
-//   k_k2p_code     pass 2   lane per chunk       the coder from (low = 0, noted range); bytes added into 32-bit sums
+//   k_k2p_zero     pass 2a  lane per chunk       zero the positions of the byte sums that are ADDED into
+//   k_k2p_code     pass 2b  lane per chunk       the coder from (low = 0, noted range); bytes added into 32-bit sums
 //   k_k2p_finish   pass 3   workgroup per slice  carries from the last byte, finish(), bytes out
 //
 // Input is the slice-major record layout (a slice's records consecutive, padded with no-op records to a multiple of 8).
@@ -11,6 +12,9 @@
 // (DESIGN.md section 4); passes 2 and 3 together take a few percent of it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <mutex>
+#include <vector>
 
 #include "avr_div.h"
 #include "avr_internal.h"
@@ -120,15 +124,7 @@ __global__ __launch_bounds__(64) void k_k2p_ranges(K2Plan p, uint32_t n_slices, 
     if (n_groups == 0) { ck_range[c0] = range; ck_pos[c0] = 0; }  // an empty slice still has its one chunk
     fin_range[s] = range;
     fin_pos[s] = pos;
-    status[s] = ok ? AVR_SLICE_OK : AVR_SLICE_ZERO_PROB;
-}
-
-// A slice whose region is too small for what passes 2 and 3 write (they ADD into the 32-bit sums at positions up to fin_pos +
-// kTail, without a bound of their own) is taken out here: AVR_SLICE_OVERFLOW, instead of sums spilling into the next slice.
-__global__ __launch_bounds__(256) void k_k2p_fits(K2Plan p, uint32_t n_slices, const uint32_t *fin_pos, int32_t *status) {
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_slices || status[s] != AVR_SLICE_OK) return;
-    if (uint64_t(fin_pos[s]) + kTail > p.out_off[s + 1] - p.out_off[s]) status[s] = AVR_SLICE_OVERFLOW;
+    status[s] = ok ? (want_status == AVR_SLICE_OK ? AVR_SLICE_OK : AVR_SLICE_DONE) : AVR_SLICE_ZERO_PROB;   // DONE: parked for the hand-over's own passes 2, 3
 }
 
 // Pass 1, double-precision form (range_step_fp, avr_k2p.h): the same chunk notes from a chain of 12 dependent
@@ -138,8 +134,12 @@ __global__ __launch_bounds__(256) void k_k2p_fits(K2Plan p, uint32_t n_slices, c
 // to k_k2p_ranges (status AVR_SLICE_RETRY_SERIAL), which covers everything.  Also validates: bit 15 of a record must be clear.
 struct TotEntry { double inv, h, d, pad; };
 struct PosEntry { double ps, nb; };
+//
+// The walk is launched in SEGMENTS of chunks [seg_begin, seg_end) of every slice (a lane picks up its range and byte count from
+// the note of chunk seg_begin, which the segment before it left): pass 2 of a segment then runs on a second stream while pass 1
+// walks the next one -- pass 1 keeps a handful of the chip's 1 024 SIMDs busy, pass 2 takes the rest (launch_k2p).
 __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
-                                                     uint64_t *fin_range, uint32_t *fin_pos, int32_t *status) {
+                                                     uint64_t *fin_range, uint32_t *fin_pos, int32_t *status, uint32_t seg_begin, uint32_t seg_end) {
     __shared__ TotEntry tot_tab[256];
     __shared__ PosEntry pos_tab[256];
     for (uint32_t d = threadIdx.x; d < 256; d += 64) {
@@ -154,11 +154,14 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slice
     const uint32_t n = p.n_bins[s], c0 = p.chunk_base[s];
     const U4 *r = reinterpret_cast<const U4 *>(p.recs + p.rec_off[s]);
     const uint32_t n_groups = (n + 7) >> 3, last = n_groups ? n_groups - 1 : 0;
-    RangeFP rg = fp_from_u64(kOne);                              // arithmetic_code.h:96-97
+    const uint32_t g_begin = seg_begin * (kChunk / 8);
+    if (seg_begin && g_begin >= n_groups) return;                // the slice ended in an earlier segment
+    const uint32_t g_end = uint64_t(seg_end) * (kChunk / 8) < n_groups ? seg_end * (kChunk / 8) : n_groups;
+    RangeFP rg = fp_from_u64(seg_begin ? ck_range[c0 + seg_begin] : kOne);          // arithmetic_code.h:96-97
     FpConsts K = fp_consts();
     asm volatile("" : "+s"(K.two32), "+s"(K.inv_two32), "+s"(K.split32), "+s"(K.two51), "+s"(K.two47));   // in scalar registers, see FpConsts
     uint32_t vmin_hi = 0xffffffffu;
-    uint32_t pos8 = 0, high = 0;                                 // pos8: BITS shifted out so far
+    uint32_t pos8 = seg_begin ? ck_pos[c0 + seg_begin] * 8u : 0u, high = 0;          // pos8: BITS shifted out so far
     auto group = [&](const U4 &v) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         high |= (w[0] | w[1]) | (w[2] | w[3]);
@@ -183,9 +186,9 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slice
         for (uint32_t k = 0; k < 4; k++) v[k] = r[g + k < last ? g + k : last];
     };
     U4 cur[4], nx1[4];
-    if (n_groups) { line(0, cur); line(4, nx1); }
-    uint32_t g = 0;
-    for (; g + 4 <= n_groups; g += 4) {
+    if (n_groups) { line(g_begin, cur); line(g_begin + 4, nx1); }
+    uint32_t g = g_begin;
+    for (; g + 4 <= g_end; g += 4) {                             // (g_end is a whole number of lines unless it is the slice's end)
         U4 nx2[4];
         line(g + 8, nx2);
         if ((g & (kChunk / 8 - 1)) == 0) note(g);
@@ -193,48 +196,78 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slice
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) { cur[k] = nx1[k]; nx1[k] = nx2[k]; }
     }
-    if (g < n_groups) {                                          // the slice's last, partial line (chunks start on whole lines)
+    if (g < g_end) {                                             // the slice's last, partial line (chunks start on whole lines)
         if ((g & (kChunk / 8 - 1)) == 0) note(g);
         group(cur[0]);
-        if (g + 1 < n_groups) group(cur[1]);
-        if (g + 2 < n_groups) group(cur[2]);
+        if (g + 1 < g_end) group(cur[1]);
+        if (g + 2 < g_end) group(cur[2]);
     }
-    if (n_groups == 0) { ck_range[c0] = kOne; ck_pos[c0] = 0; }
-    fin_range[s] = fp_to_u64(rg);
-    fin_pos[s] = pos8 >> 3;
+    if (g_end < n_groups) note(g_end);                           // where the next segment picks up
+    else {
+        if (n_groups == 0) { ck_range[c0] = kOne; ck_pos[c0] = 0; }
+        fin_range[s] = fp_to_u64(rg);
+        fin_pos[s] = pos8 >> 3;
+    }
     if (high & 0x80008000u) status[s] = AVR_SLICE_BAD_RECORD;
     else if (vmin_hi < kTwo39Hi) status[s] = AVR_SLICE_RETRY_SERIAL;   // the integer form walks it again, from the start
 }
 
-// Between the passes: the positions that will be ADDED into are zeroed -- the first kTail of every chunk (where earlier chunks
-// may leave bytes of their low) and the kTail behind the slice's last byte; every other position gets one plain store.
-__global__ __launch_bounds__(256) void k_k2p_zero(K2Plan p, uint32_t total_chunks, const uint32_t *ck_pos, const uint32_t *fin_pos,
-                                                 const int32_t *status, uint32_t *S) {
-    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
-    if (gc >= total_chunks) return;
-    const uint32_t s = p.chunk_slice[gc];
-    if (status[s] != AVR_SLICE_OK) return;
-    uint32_t *at = S + p.out_off[s] + ck_pos[gc];
-    for (uint32_t j = 0; j < kTail; j++) at[j] = 0;
-    if (gc + 1 == p.chunk_base[s + 1]) {                         // the slice's last chunk: also behind its last byte
-        uint32_t *end = S + p.out_off[s] + fin_pos[s];
-        for (uint32_t j = 0; j < kTail; j++) end[j] = 0;
+// Which chunk a lane of passes 2a / 2b takes.  seg_len > 0: lane i takes chunk seg_begin + i % seg_len of slice i / seg_len (a
+// segment of every slice, lanes packed); seg_len == 0: lane i takes global chunk i if it lies at or behind seg_begin in its
+// slice (the last, open-ended segment -- and the whole slice when there is only one).  Returns false when there is nothing to do:
+// no such chunk, a slice whose status is not `want`, or a chunk that would write past the slice's region, in which case the slice
+// is flagged AVR_SLICE_OVERFLOW here (positions grow along the slice: the chunks before it fitted, the ones behind it do not).
+struct ChunkPick { uint32_t s, gc, c, n, last; };
+__device__ __forceinline__ bool pick_chunk(const K2Plan &p, uint32_t i, uint32_t n_slices, uint32_t total_chunks, uint32_t seg_begin, uint32_t seg_len,
+                                           const uint32_t *ck_pos, const uint32_t *fin_pos, int32_t *status, int32_t want, ChunkPick *o) {
+    uint32_t s, gc;
+    if (seg_len) {
+        s = i / seg_len;
+        if (s >= n_slices) return false;
+        const uint32_t c = seg_begin + (i - s * seg_len);
+        gc = p.chunk_base[s] + c;
+        if (gc >= p.chunk_base[s + 1]) return false;
+    } else {
+        gc = i;
+        if (gc >= total_chunks) return false;
+        s = p.chunk_slice[gc];
+        if (gc - p.chunk_base[s] < seg_begin) return false;
     }
+    if (status[s] != want) return false;
+    o->s = s; o->gc = gc; o->c = gc - p.chunk_base[s]; o->n = p.n_bins[s];
+    o->last = gc + 1 == p.chunk_base[s + 1];
+    const uint32_t end_pos = o->last ? fin_pos[s] : ck_pos[gc + 1];
+    if (uint64_t(end_pos) + kTail > p.out_off[s + 1] - p.out_off[s]) { status[s] = AVR_SLICE_OVERFLOW; return false; }
+    return true;
+}
+
+// Pass 2a: the positions that will be ADDED into are zeroed; every other position gets one plain store.  Added into are the kTail
+// positions from every chunk's end on (its own left-over low, the first bytes of the chunk behind it, and, at the slice's end, what
+// finish() reads), and the first kTail of the slice.  A chunk's lane zeroes those behind ITS end that the chunk before it has not
+// already zeroed -- [max(end, start + kTail), end + kTail) -- so that no position is zeroed twice: with the passes running segment
+// by segment, a second zeroing would come after the adds of the segment before.
+__global__ __launch_bounds__(256) void k_k2p_zero(K2Plan p, uint32_t n_slices, uint32_t total_chunks, const uint32_t *ck_pos, const uint32_t *fin_pos,
+                                                 int32_t *status, uint32_t *S, int32_t want, uint32_t seg_begin, uint32_t seg_len) {
+    ChunkPick k;
+    if (!pick_chunk(p, blockIdx.x * 256 + threadIdx.x, n_slices, total_chunks, seg_begin, seg_len, ck_pos, fin_pos, status, want, &k)) return;
+    uint32_t *base = S + p.out_off[k.s];
+    const uint32_t start = ck_pos[k.gc], end = k.last ? fin_pos[k.s] : ck_pos[k.gc + 1];
+    if (k.c == 0)
+        for (uint32_t j = 0; j < kTail; j++) base[j] = 0;
+    for (uint32_t j = end > start + kTail ? end : start + kTail; j < end + kTail; j++) base[j] = 0;
 }
 
 // Pass 2.  One lane per chunk: the coder itself over the chunk's bins, from low = 0 and the range noted by pass 1; every
 // byte it shifts out (carry bit included) is added to the sum of its position in the slice, and what is left of low at
 // the end to the kTail positions behind.  Lanes of neighbouring chunks add into the same positions where they meet.
-__global__ __launch_bounds__(256) void k_k2p_code(K2Plan p, uint32_t total_chunks, const uint64_t *ck_range, const uint32_t *ck_pos,
-                                                 const int32_t *status, uint32_t *S) {
+__global__ __launch_bounds__(256) void k_k2p_code(K2Plan p, uint32_t n_slices, uint32_t total_chunks, const uint64_t *ck_range, const uint32_t *ck_pos,
+                                                 const uint32_t *fin_pos, int32_t *status, uint32_t *S, int32_t want, uint32_t seg_begin, uint32_t seg_len) {
     __shared__ double inv[256];
     fill_inv(inv);
     __syncthreads();
-    const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
-    if (gc >= total_chunks) return;
-    const uint32_t s = p.chunk_slice[gc];
-    if (status[s] != AVR_SLICE_OK) return;
-    const uint32_t c = gc - p.chunk_base[s], n = p.n_bins[s], i0 = c * kChunk;
+    ChunkPick k;
+    if (!pick_chunk(p, blockIdx.x * 256 + threadIdx.x, n_slices, total_chunks, seg_begin, seg_len, ck_pos, fin_pos, status, want, &k)) return;
+    const uint32_t s = k.s, gc = k.gc, n = k.n, i0 = k.c * kChunk;
     const uint32_t i1 = i0 + kChunk < n ? i0 + kChunk : n;
     const uint16_t *r = p.recs + p.rec_off[s];
     uint32_t *at = S + p.out_off[s] + ck_pos[gc];
@@ -266,12 +299,15 @@ __global__ __launch_bounds__(256) void k_k2p_code(K2Plan p, uint32_t total_chunk
 // applied as it stands.
 constexpr uint32_t kFinTile = 4096, kFinSeg = kFinTile / 64, kFinRow = kFinSeg + 1;   // a lane's segment, padded by one word: no bank conflicts
 __global__ __launch_bounds__(64) void k_k2p_finish(K2Plan p, const uint64_t *fin_range, const uint32_t *fin_pos, const uint32_t *S,
-                                                  uint8_t *out, uint32_t *out_len, int32_t *status) {
+                                                  uint8_t *out, uint32_t *out_len, int32_t *status, int32_t want) {
     __shared__ uint32_t dig[64 * kFinRow];
     __shared__ uint32_t cout[65];
     __shared__ uint8_t tail_bytes[kTail];
     const uint32_t s = blockIdx.x, t = threadIdx.x;
-    if (status[s] != AVR_SLICE_OK) { if (t == 0) out_len[s] = 0; return; }
+    if (status[s] != want) {                                     // (a slice parked as DONE is the hand-over launch's to finish)
+        if (t == 0 && want == AVR_SLICE_OK && status[s] != AVR_SLICE_DONE) out_len[s] = 0;
+        return;
+    }
     const uint32_t P = fin_pos[s];
     const uint32_t *Ss = S + p.out_off[s];
     uint8_t *o = out + p.out_off[s];
@@ -320,7 +356,7 @@ __global__ __launch_bounds__(64) void k_k2p_finish(K2Plan p, const uint64_t *fin
             if (P + k < cap) o[P + k] = tail[k];
         for (uint32_t i = P < cap ? P : cap; cy && i-- > 0;) { const uint32_t b = uint32_t(o[i]) + 1u; o[i] = uint8_t(b); cy = b >> 8; }
         out_len[s] = P + n_tail;
-        if (P + n_tail > cap) status[s] = AVR_SLICE_OVERFLOW;
+        status[s] = P + n_tail > cap ? AVR_SLICE_OVERFLOW : AVR_SLICE_OK;
     }
 }
 
@@ -334,10 +370,36 @@ size_t k2p_workspace_bytes(size_t n_slices, uint32_t total_chunks, uint64_t out_
                   up256(out_total * 4 + 64));
 }
 
+// The second stream pass 2 runs on while pass 1 walks on, with its events: one set per (device, caller's stream), made on
+// first use and kept (work on the caller's stream is ordered, so consecutive calls may share it).
+namespace {
+constexpr uint32_t kMaxSegments = 8;
+struct Side { int dev; hipStream_t main, side; hipEvent_t seg[kMaxSegments], join; };
+hipError_t side_stream(hipStream_t s, Side **out) {
+    static std::vector<Side *> pool;
+    static std::mutex mu;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (Side *x : pool)
+        if (x->dev == dev && x->main == s) { *out = x; return hipSuccess; }
+    Side *x = new Side{dev, s, nullptr, {}, nullptr};
+    if ((e = hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking)) != hipSuccess) { delete x; return e; }
+    for (uint32_t k = 0; k < kMaxSegments && e == hipSuccess; k++) e = hipEventCreateWithFlags(&x->seg[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&x->join, hipEventDisableTiming);
+    if (e != hipSuccess) { delete x; return e; }
+    pool.push_back(x);
+    *out = x;
+    return hipSuccess;
+}
+}  // namespace
+
 hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins, uint32_t n_slices,
                       const uint32_t *chunk_base, const uint32_t *chunk_slice, uint32_t total_chunks, uint64_t out_total,
                       void *workspace, uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status) {
     if (n_slices == 0) return hipSuccess;
+    (void)out_total;
     uint8_t *w = static_cast<uint8_t *>(workspace);
     uint64_t *ck_range = reinterpret_cast<uint64_t *>(w);    w += up256(uint64_t(total_chunks) * 8);
     uint32_t *ck_pos = reinterpret_cast<uint32_t *>(w);      w += up256(uint64_t(total_chunks) * 4);
@@ -345,13 +407,40 @@ hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
     uint32_t *fin_pos = reinterpret_cast<uint32_t *>(w);     w += up256(uint64_t(n_slices) * 4);
     uint32_t *S = reinterpret_cast<uint32_t *>(w);
     const K2Plan p{recs, rec_off, n_bins, chunk_base, chunk_slice, out_off};
-    hipLaunchKernelGGL(k_k2p_ranges_fp, dim3((n_slices + 63) / 64), dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status);
-    hipLaunchKernelGGL(k_k2p_ranges, dim3((n_slices + 63) / 64), dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status,
-                       AVR_SLICE_RETRY_SERIAL);
-    hipLaunchKernelGGL(k_k2p_fits, dim3((n_slices + 255) / 256), dim3(256), 0, s, p, n_slices, fin_pos, status);
-    hipLaunchKernelGGL(k_k2p_zero, dim3((total_chunks + 255) / 256), dim3(256), 0, s, p, total_chunks, ck_pos, fin_pos, status, S);
-    hipLaunchKernelGGL(k_k2p_code, dim3((total_chunks + 255) / 256), dim3(256), 0, s, p, total_chunks, ck_range, ck_pos, status, S);
-    hipLaunchKernelGGL(k_k2p_finish, dim3(n_slices), dim3(64), 0, s, p, fin_range, fin_pos, S, out, out_len, status);
+    const dim3 slice_grid((n_slices + 63) / 64), chunk_grid((total_chunks + 255) / 256);
+    // Segments: an eighth of the average slice each, the last one open-ended (it takes whatever the longer slices have left).
+    const uint32_t avg = total_chunks / n_slices;
+    uint32_t seg_len = avg >= 32 ? (avg + kMaxSegments - 1) / kMaxSegments : 0;
+    if (test_hooks().k2p_seg_len) seg_len = test_hooks().k2p_seg_len;       // test build only: short slices through many segments
+    const uint32_t n_seg = seg_len ? kMaxSegments : 1;
+    Side *side = nullptr;
+    hipError_t e;
+    if (n_seg > 1 && (e = side_stream(s, &side)) != hipSuccess) return e;
+    hipStream_t s2 = side ? side->side : s;
+    for (uint32_t k = 0; k < n_seg; k++) {
+        const bool open = k + 1 == n_seg;
+        const uint32_t begin = k * seg_len, end = open ? 0xffffffffu / kChunk : begin + seg_len;
+        hipLaunchKernelGGL(k_k2p_ranges_fp, slice_grid, dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, begin, end);
+        if (side) {
+            if ((e = hipEventRecord(side->seg[k], s)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(s2, side->seg[k], 0)) != hipSuccess) return e;
+        }
+        const dim3 grid = open ? chunk_grid : dim3(uint32_t((uint64_t(n_slices) * seg_len + 255) / 256));
+        const uint32_t len = open ? 0 : seg_len;
+        hipLaunchKernelGGL(k_k2p_zero, grid, dim3(256), 0, s2, p, n_slices, total_chunks, ck_pos, fin_pos, status, S, AVR_SLICE_OK, begin, len);
+        hipLaunchKernelGGL(k_k2p_code, grid, dim3(256), 0, s2, p, n_slices, total_chunks, ck_range, ck_pos, fin_pos, status, S, AVR_SLICE_OK, begin, len);
+    }
+    if (side) {
+        if ((e = hipEventRecord(side->join, s2)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(s, side->join, 0)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_k2p_finish, dim3(n_slices), dim3(64), 0, s, p, fin_range, fin_pos, S, out, out_len, status, AVR_SLICE_OK);
+    // The slices the double-precision walk handed over (AVR_SLICE_RETRY_SERIAL: a range below 2^39 somewhere), start to end in the
+    // integer form; a workgroup without any leaves at once, so these four launches cost microseconds when there is none.
+    hipLaunchKernelGGL(k_k2p_ranges, slice_grid, dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, AVR_SLICE_RETRY_SERIAL);
+    hipLaunchKernelGGL(k_k2p_zero, chunk_grid, dim3(256), 0, s, p, n_slices, total_chunks, ck_pos, fin_pos, status, S, AVR_SLICE_DONE, 0u, 0u);
+    hipLaunchKernelGGL(k_k2p_code, chunk_grid, dim3(256), 0, s, p, n_slices, total_chunks, ck_range, ck_pos, fin_pos, status, S, AVR_SLICE_DONE, 0u, 0u);
+    hipLaunchKernelGGL(k_k2p_finish, dim3(n_slices), dim3(64), 0, s, p, fin_range, fin_pos, S, out, out_len, status, AVR_SLICE_DONE);
     return hipGetLastError();
 }
 

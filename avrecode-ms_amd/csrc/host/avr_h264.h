@@ -307,10 +307,35 @@ struct mb_info {
     mb_info() { memset(cbf, 0, sizeof cbf); memset(ref, 0, sizeof ref); memset(mvd, 0, sizeof mvd); }
 };
 
-struct model_hooks {                                     // the two model callbacks the reference's fork does fire (recode.cpp:173, :177)
+struct model_hooks {                                     // the six model callbacks of recode.cpp:172-216
     host::hooks *h = nullptr;
+    // frame_spec and mb_xy are the two the reference's fork does fire ("Called", recode.cpp:173, :177).  The other four are
+    // annotated "Not called" there (:182, :190, :204, :210); `residual` makes this parser fire them around every residual
+    // block -- begin_sub_mb before its coded_block_flag, PIP_SIGNIFICANCE_MAP around its significance map, end_sub_mb after
+    // its levels -- which is what brings h264_model's significance-map keys and the recorders' queueing (recode.cpp:683-822,
+    // 851-1033, 1201-1262, 1483-1505) to life on real streams (h264_stream_decoder::residual_hooks).
+    bool residual = false;
+    // The reference sends a block's nonzero count ahead of its map in 2, 4 or 6 bits for blocks of up to 4, 16 or more
+    // coefficients (recode.cpp:865: serialized_bits) -- a count of 4, 16 or 64 does not fit, and its decompressor would then
+    // infer the wrong end of block.  (The path is dead code there, "Not called"; nothing ever ran into it.)  This build keeps the
+    // reference's widths and makes the parser refuse such a slice instead when it dry-runs a payload for the compressor
+    // (h264_stream_decoder::payload_decodes): the slice stays a literal block, the file stays lossless.
+    bool refuse_full_blocks = false;
+    static int count_limit(int max_coeff) { return max_coeff > 16 ? 64 : max_coeff > 4 ? 16 : 4; }
     void frame_spec(int frame_num, int w, int hh) const { if (h && h->model.frame_spec) h->model.frame_spec(h->opaque, frame_num, w, hh); }
     void mb_xy(int x, int y) const { if (h && h->model.mb_xy) h->model.mb_xy(h->opaque, x, y); }
+    void begin_sub_mb(int cat, int n, int max_coeff, int dc, int c422) const {
+        if (residual && h && h->model.begin_sub_mb) h->model.begin_sub_mb(h->opaque, cat, n, max_coeff, dc, c422);
+    }
+    void end_sub_mb(int cat, int n, int max_coeff, int dc, int c422) const {
+        if (residual && h && h->model.end_sub_mb) h->model.end_sub_mb(h->opaque, cat, n, max_coeff, dc, c422);
+    }
+    void begin_significance_map() const {
+        if (residual && h && h->model.begin_coding_type) h->model.begin_coding_type(h->opaque, int(host::PIP_SIGNIFICANCE_MAP), 0, 0, 0);
+    }
+    void end_significance_map() const {
+        if (residual && h && h->model.end_coding_type) h->model.end_coding_type(h->opaque, int(host::PIP_SIGNIFICANCE_MAP));
+    }
 };
 
 template <class Bins>
@@ -629,18 +654,12 @@ class slice_parser {
         if (cat == 1 || cat == 2) {
             const int n_dc = 4 * (cat == 2 ? 2 : 1);
             if (cur_->cbp_chroma & 3)
-                for (int c = 0; c < 2; c++) {
-                    const int cbf = coded_block_flag(3, c + 1, -1, true);
-                    cur_->dc_cbf[c + 1] = uint8_t(cbf);
-                    if (cbf) coefficients(3, n_dc);
-                }
+                for (int c = 0; c < 2; c++) cur_->dc_cbf[c + 1] = uint8_t(block(3, c + 1, -1, true, n_dc, 49 + c));      // CHROMA_DC_BLOCK_INDEX + c
             if (cur_->cbp_chroma & 2)
                 for (int c = 0; c < 2; c++)
                     for (int blk = 0; blk < n_dc; blk++) {
                         const int x = blk & 1, y = blk >> 1;
-                        const int cbf = coded_block_flag(4, c + 1, y * 4 + x, false);
-                        cur_->cbf[c + 1][y * 4 + x] = uint8_t(cbf);
-                        if (cbf) coefficients(4, 15);
+                        cur_->cbf[c + 1][y * 4 + x] = uint8_t(block(4, c + 1, y * 4 + x, false, 15, 16 * (c + 1) + blk));
                     }
         } else if (cat == 3) {
             residual_plane(1, i16x16);                                   // Cb, Cr coded like luma with their own categories
@@ -651,30 +670,34 @@ class slice_parser {
     // luma, or a 4:4:4 chroma plane: DC / AC of Intra16x16, 4x4 or 8x8 blocks per 8x8 quadrant with its cbp bit
     void residual_plane(int plane, bool i16x16) {
         const int cat_dc = plane == 0 ? 0 : plane == 1 ? 6 : 10, cat_ac = cat_dc + 1, cat_4x4 = cat_dc + 2, cat_8x8 = plane == 0 ? 5 : plane == 1 ? 9 : 13;
-        if (i16x16) {
-            const int cbf = coded_block_flag(cat_dc, plane, -1, true);
-            cur_->dc_cbf[plane] = uint8_t(cbf);
-            if (cbf) coefficients(cat_dc, 16);
-        }
+        if (i16x16) cur_->dc_cbf[plane] = uint8_t(block(cat_dc, plane, -1, true, 16, 48 + plane));       // LUMA_DC_BLOCK_INDEX + plane
         for (int q = 0; q < 4; q++) {
             if (!((cur_->cbp_luma >> q) & 1)) continue;
             const int x0 = (q & 1) * 2, y0 = (q >> 1) * 2;
             if (cur_->transform8x8) {
                 // the coded_block_flag of an 8x8 block is only sent with 4:4:4 (7.3.5.3.3); otherwise it is inferred 1
-                int cbf = 1;
-                if (h_.chroma_array_type == 3) cbf = coded_block_flag(cat_8x8, plane, y0 * 4 + x0, false);
+                const int cbf = block(cat_8x8, plane, y0 * 4 + x0, false, 64, 16 * plane + 4 * q, h_.chroma_array_type == 3);
                 for (int k = 0; k < 4; k++) cur_->cbf[plane][(y0 + (k >> 1)) * 4 + x0 + (k & 1)] = uint8_t(cbf);
-                if (cbf) coefficients(cat_8x8, 64);
             } else {
                 for (int k = 0; k < 4; k++) {
                     const int x = x0 + (k & 1), y = y0 + (k >> 1);
-                    const int cat = i16x16 ? cat_ac : cat_4x4;
-                    const int cbf = coded_block_flag(cat, plane, y * 4 + x, false);
-                    cur_->cbf[plane][y * 4 + x] = uint8_t(cbf);
-                    if (cbf) coefficients(cat, i16x16 ? 15 : 16);
+                    cur_->cbf[plane][y * 4 + x] = uint8_t(block(i16x16 ? cat_ac : cat_4x4, plane, y * 4 + x, false, i16x16 ? 15 : 16, 16 * plane + 4 * q + k));
                 }
             }
         }
+    }
+
+    // One residual block: its coded_block_flag (inferred 1 when `sent` is false), then residual_block_cabac().  `n` is the block's
+    // number the way libavcodec counts them for its decode_cabac_residual calls -- 4 * (8x8 quadrant) + (4x4 inside it) for
+    // luma, + 16 per colour plane, 48 + plane for an Intra16x16 DC block, 49 + c for a chroma DC block -- which is what the
+    // model hooks are given as `scan8index` (recode.cpp:182) and what h264_model keeps the nonzero counts by.
+    int block(int cat, int plane, int blk, bool dc, int max_coeff, int n, bool sent = true) {
+        const int c422 = dc && cat == 3 && h_.chroma_array_type == 2;
+        model_.begin_sub_mb(cat, n, max_coeff, dc, c422);
+        const int cbf = sent ? coded_block_flag(cat, plane, blk, dc) : 1;
+        if (cbf) coefficients(cat, max_coeff);
+        model_.end_sub_mb(cat, n, max_coeff, dc, c422);
+        return cbf;
     }
 
     // 9.3.3.1.1.9: transBlockN's coded_block_flag, with the rules for N unavailable / skipped / without the cbp bit
@@ -706,6 +729,7 @@ class slice_parser {
         const int sig = kSigBase[cat], last = kLastBase[cat], abs_base = kAbsBase[cat];
         int n = 0;
         int i = 0;
+        model_.begin_significance_map();
         for (; i < max_coeff - 1; i++) {
             int inc_s, inc_l;
             if (is8x8) { inc_s = kSig8x8[i]; inc_l = kLast8x8[i]; }
@@ -717,6 +741,9 @@ class slice_parser {
             }
         }
         if (i == max_coeff - 1) n++;                                     // the last coefficient is significant by inference
+        if (model_.refuse_full_blocks && n >= model_hooks::count_limit(max_coeff))
+            throw unsupported("a block with as many nonzero coefficients as the reference's count field cannot hold (recode.cpp:865)");
+        model_.end_significance_map();
         int gt1 = 0, eq1 = 0;
         for (int k = 0; k < n; k++) {                                    // coeff_abs_level_minus1 (prefix TU 14, suffix EG0), then the sign
             const int ctx0 = abs_base + (gt1 ? 0 : (1 + eq1 < 4 ? 1 + eq1 : 4));
@@ -875,6 +902,11 @@ inline bool mp4_nals(const std::vector<uint8_t> &d, std::vector<nal_ref> *out) {
 class h264_stream_decoder : public host::stream_decoder {
   public:
     struct stats_t { size_t slices = 0, hooked = 0, unsupported = 0, failed = 0, macroblocks = 0; std::string last_reason; } stats;
+    // Fire begin / end_sub_mb and begin / end_coding_type around residual blocks (model_hooks::residual): all eleven hooks of
+    // recode.cpp:219-235 are then live, h264_model keys significance-map bins by position and nonzero count, and the
+    // recorders queue them behind the block's nonzero count.  Off by default, as in the reference's fork ("Not called").
+    // Both directions of a file must agree on it (the container does not say which model wrote it).
+    bool residual_hooks = false;
 
     void decode_video(host::hooks *h, int (*read_packet)(void *, uint8_t *, int), void *opaque) override {
         std::vector<uint8_t> data, chunk(1 << 16);
@@ -907,7 +939,9 @@ class h264_stream_decoder : public host::stream_decoder {
             engine_bins bins(offered_payload_, offered_size_);
             uint8_t states[1024];
             std::vector<mb_info> scratch(mbs_.size());
-            slice_parser<engine_bins> p(bins, offered_header_, states, scratch, 0, model_hooks());
+            model_hooks dry;                             // no hooks fire; with the residual hooks on, the counts must fit their fields
+            dry.refuse_full_blocks = residual_hooks;
+            slice_parser<engine_bins> p(bins, offered_header_, states, scratch, 0, dry);
             p.run();
             return ends_cleanly(bins.d.bit_position(), offered_payload_, offered_size_);
         } catch (const std::exception &e) {
@@ -938,6 +972,12 @@ class h264_stream_decoder : public host::stream_decoder {
             sh.x264_old_444_cbf = sh.chroma_array_type == 3 && x264_build_ >= 0 && x264_build_ < 151;
         } catch (const unsupported &e) { stats.unsupported++; stats.last_reason = e.what(); return; }
         catch (const bad_stream &e) { stats.failed++; stats.last_reason = e.what(); return; }
+        // What frame_spec is told (recode.cpp:173): a number that is the same for the slices of a picture and differs from one
+        // picture to the next.  frame_num itself repeats across a non-reference picture and the one after it, and h264_model
+        // clears its per-picture store only when the number changes (update_frame_spec, recode.cpp:831-850): with the residual
+        // hooks on, what an earlier picture left in a block would be counted into this picture's nonzero counts.
+        if (sh.first_mb == 0 || pictures_ == 0) pictures_++;
+        sh.frame_num = pictures_;
         const size_t n_mbs = size_t(sh.width_mbs) * sh.height_mbs;
         if (mbs_.size() != n_mbs) mbs_.assign(n_mbs, mb_info());
         const uint8_t *payload = rbsp.data() + sh.data_offset;
@@ -948,7 +988,7 @@ class h264_stream_decoder : public host::stream_decoder {
         if (!dec) return;                                // not hooked: nothing of this slice is needed later (no reconstruction)
         stats.hooked++;
         hook_bins bins{h, dec};
-        slice_parser<hook_bins> p(bins, sh, cabac_state_, mbs_, ++slice_counter_, model_hooks{h});
+        slice_parser<hook_bins> p(bins, sh, cabac_state_, mbs_, ++slice_counter_, model_hooks{h, residual_hooks});
         stats.macroblocks += size_t(p.run());
     }
 
@@ -972,7 +1012,7 @@ class h264_stream_decoder : public host::stream_decoder {
     std::vector<mb_info> mbs_;
     uint8_t cabac_state_[1024];                          // the addresses get() hands to the hooks, as libavcodec's sl->cabac_state
     int cabac_context_identity_ = 0;                     // stands for the one CABACContext of a single-threaded decode (recode.cpp:153)
-    int slice_counter_ = 0;
+    int slice_counter_ = 0, pictures_ = 0;
     bool offered_ = false;
     const uint8_t *offered_payload_ = nullptr;
     size_t offered_size_ = 0;

@@ -195,14 +195,25 @@ class compress_recorder {
         }
     }
     void end_coding_type(CodingType ct) {                                               // :1210-1236
+        // One deliberate difference from recode.cpp:1214-1218.  The keys of the count's bits include the macroblock's "has an
+        // 8x8 block" flag (meta.is_8x8, :889), and model->end_coding_type sets that flag for the block just ended (:962).  The
+        // reference's compressor calls it BEFORE finished_queueing, its decompressor decodes the count at begin_coding_type,
+        // i.e. before (:1483-1492): for the first 8x8 block of a macroblock the two sides of the reference use different
+        // estimators and its decoder loses the stream (the path is never run there: the hooks are "Not called", :182-210).
+        // A container has to decode, so this side codes the count with the flag as the decoder will see it -- as it was
+        // when the block began.
+        const bool had_8x8 = model_->current_block_flag_8x8();
         model_->end_coding_type(ct);
         if (ct != PIP_SIGNIFICANCE_MAP && ct != PIP_SIGNIFICANCE_EOB) return;
         if (queueing_ == PIP_UNKNOWN) throw std::runtime_error("compress_recorder: end of a coding type that was not begun");         // :1250
         queueing_ = PIP_UNKNOWN;
+        const bool has_8x8 = model_->current_block_flag_8x8();
+        model_->set_current_block_flag_8x8(had_8x8);
         model_->finished_queueing(ct, [&](const model_key &key, int *symbol) {          // the nonzero count first ...
             record(*symbol, key);
             model_->update_state_for_model_key(*symbol, key);
         });
+        model_->set_current_block_flag_8x8(has_8x8);
         model_->reset_mb_significance_state_tracking();                                 // ... then the map (:1254-1265)
         for (const queued &q : queue_) execute(q.symbol, q.context);
         queue_.clear();

@@ -326,6 +326,9 @@ class h264_model {
         update_state_tracking(symbol);
     }
     void update_state(int symbol, int context) { update_state_for_model_key(symbol, get_model_key(context)); }   // :1034-1036
+    // BlockMeta::is_8x8 of the macroblock being coded (block.h:22), for compress_recorder::end_coding_type
+    bool current_block_flag_8x8() const { return current_meta().is_8x8; }
+    void set_current_block_flag_8x8(bool v) { current_meta().is_8x8 = v; }
 
   private:
     frame_store::mb_meta &current_meta() { return frames[cur_frame].meta_at(mb_coord.mb_x, mb_coord.mb_y); }

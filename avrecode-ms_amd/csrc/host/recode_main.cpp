@@ -10,7 +10,9 @@
 // One more command, `recode probe <input>`: parse every slice with the build's own CABAC engine and report how many
 // parse to their end (no GPU, nothing written) -- what tests/test_h264.py pins the parser and its tables with.
 //
-// Environment: AVR_DEVICE = HIP device index (default 0).
+// Environment: AVR_DEVICE = HIP device index (default 0); AVR_MODEL_HOOKS=1 = the stream decoder also fires begin / end_sub_mb
+// and begin / end_coding_type around residual blocks (all eleven hooks of recode.cpp:219-235 live: the significance-map side of
+// h264_model), for compress AND decompress of the same file -- the reference's fork leaves those four uncalled, so off by default.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +30,7 @@ namespace {
 using namespace avr;
 
 int device() { const char *d = getenv("AVR_DEVICE"); return d ? atoi(d) : 0; }
+bool model_hooks() { const char *d = getenv("AVR_MODEL_HOOKS"); return d && atoi(d) != 0; }
 
 std::string slurp(const std::string &path) {
     std::ifstream f(path, std::ios::binary);
@@ -40,12 +43,14 @@ std::string slurp(const std::string &path) {
 std::string compress_bytes(const std::string &original) {            // compressor::run, recode.cpp:1122-1132
     host::compressor c(original, device());
     h264::h264_stream_decoder d;
+    d.residual_hooks = model_hooks();
     return c.run(&d);
 }
 
 std::string decompress_bytes(const std::string &recoded) {           // decompressor::run, recode.cpp:1345-1364
     host::decompressor d(recoded, device());
     h264::h264_stream_decoder dec;
+    dec.residual_hooks = model_hooks();
     return d.run(&dec);
 }
 

@@ -14,13 +14,6 @@ def shard_first_slice(rank: int, slices_per_rank: int) -> int:
     return rank * slices_per_rank
 
 
-def shard_range(total_slices: int, rank: int, world: int):
-    """Strong-scaling split of `total_slices` into near-equal contiguous ranges."""
-    base, extra = divmod(total_slices, world)
-    lo = rank * base + min(rank, extra)
-    return lo, lo + base + (1 if rank < extra else 0)
-
-
 def lpt_assign(n_bins, world: int):
     """Greedy LPT: slices longest first, each to the rank with the least bins so far (ties: the lower rank).
     Returns the rank of every slice.  Same plan as avr_multi_run (csrc/avr_api.cpp)."""

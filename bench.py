@@ -362,6 +362,7 @@ def main():
             "config": {"workload": WORKLOAD_NAME[args.workload], "kernel": "K1 cabac_encode" if kind == avr.KIND_CABAC else "K2 range_encode",
                        "slices_per_gpu": n_slices, "batch_slices": batch_slices if args.scaling == "strong" else n_slices * world,
                        "bins_per_gpu": w.total_bins, "h264_bytes_per_gpu": out_bytes,
+                       "h264_bytes_all_gpus": total_bytes // max(args.steps, 1),
                        "n_states": w.n_states, "n_states_declared": declared_states,
                        "layout": "slice-major" if path == "chunked" else "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "host/avr_recode.h"
+#include "host/avr_h264.h"
 
 using namespace avr::host;
 
@@ -160,10 +161,24 @@ struct cpu_compress_driver {
     context_ids ids;
     std::vector<uint16_t> recs;                           // K2 records of all slices
     std::vector<uint64_t> rec_end;                        // running end per slice
+    std::vector<uint8_t> payloads;                        // the payload every init_decoder was given, back to back
+    std::vector<uint64_t> payload_end;
+    stream_decoder *decoder = nullptr;                    // asked, like compressor does, whether it will get through the payload
+    std::vector<uint8_t> offered;                         // per slice offered: 1 = hooked
     struct cabac_decoder {
-        cabac_decoder(cpu_compress_driver *d, const uint8_t *buf, int size) : d_(d), dec_(buf, size_t(size)), rec_(&d->model_) {}
-        ~cabac_decoder() { d_->recs.insert(d_->recs.end(), rec_.records().begin(), rec_.records().end()); d_->rec_end.push_back(d_->recs.size()); }
-        bool hooked() const { return true; }
+        cabac_decoder(cpu_compress_driver *d, const uint8_t *buf, int size) : d_(d), dec_(buf, size_t(size)), rec_(&d->model_) {
+            hooked_ = !d->decoder || d->decoder->payload_decodes();
+            d->offered.push_back(hooked_);
+            if (!hooked_) return;
+            d->payloads.insert(d->payloads.end(), buf, buf + size);
+            d->payload_end.push_back(d->payloads.size());
+        }
+        ~cabac_decoder() {
+            if (!hooked_) return;
+            d_->recs.insert(d_->recs.end(), rec_.records().begin(), rec_.records().end()); d_->rec_end.push_back(d_->recs.size());
+        }
+        bool hooked() const { return hooked_; }
+        bool hooked_ = true;
         int get(uint8_t *state) { const int s = dec_.get(state); rec_.execute_symbol(s, d_->ids.id_of(state)); return s; }
         int get_bypass() { const int s = dec_.get_bypass(); rec_.execute_symbol(s, kKeyBypass); return s; }
         int get_terminate() { const int s = dec_.get_terminate() != 0; rec_.execute_symbol(s, kKeyTerminate); return s; }
@@ -181,17 +196,29 @@ struct cpu_decompress_driver {
     const uint8_t *recoded = nullptr; const uint64_t *recoded_off = nullptr; size_t next = 0;   // per-slice recoded bytes
     std::vector<uint16_t> recs;                           // K1 records of all slices
     std::vector<uint64_t> rec_end;
+    std::vector<uint8_t> first_states;                    // per slice: *state at every context's first bin (1024 each), by context id
+    std::vector<int32_t> n_states;
+    const uint8_t *offered = nullptr; size_t n_offered = 0, at_offered = 0;   // which of the slices offered were hooked on the way in (null: all)
     struct cabac_decoder {
         cabac_decoder(cpu_decompress_driver *d, const uint8_t *, int)
-            : d_(d), rec_(&d->model_, d->recoded + d->recoded_off[d->next], size_t(d->recoded_off[d->next + 1] - d->recoded_off[d->next]), &d->ids) { d->next++; }
-        ~cabac_decoder() { d_->recs.insert(d_->recs.end(), rec_.records().begin(), rec_.records().end()); d_->rec_end.push_back(d_->recs.size()); }
-        bool hooked() const { return true; }
+            : d_(d), hooked_(!d->offered || (d->at_offered < d->n_offered && d->offered[d->at_offered])),
+              rec_(&d->model_, d->recoded + d->recoded_off[d->next], hooked_ ? size_t(d->recoded_off[d->next + 1] - d->recoded_off[d->next]) : 0, &d->ids) {
+            d->at_offered++;
+            if (hooked_) d->next++;
+        }
+        ~cabac_decoder() {
+            if (!hooked_) return;
+            d_->recs.insert(d_->recs.end(), rec_.records().begin(), rec_.records().end()); d_->rec_end.push_back(d_->recs.size());
+            d_->first_states.insert(d_->first_states.end(), rec_.init_states(), rec_.init_states() + 1024);
+            d_->n_states.push_back(rec_.n_states());
+        }
+        bool hooked() const { return hooked_; }
         int get(uint8_t *state) { return rec_.get(state); }
         int get_bypass() { return rec_.get_bypass(); }
         int get_terminate() { return rec_.get_terminate(); }
         void begin_coding_type(CodingType ct, int z, int p0, int p1) { rec_.begin_coding_type(ct, z, p0, p1); }
         void end_coding_type(CodingType ct) { rec_.end_coding_type(ct); }
-        cpu_decompress_driver *d_; decompress_recorder rec_;
+        cpu_decompress_driver *d_; bool hooked_; decompress_recorder rec_;
     };
     h264_model *get_model() { return &model_; }
     std::map<void *, std::unique_ptr<cabac_decoder>> cabac_contexts;
@@ -367,6 +394,62 @@ void t_neighbor_block(int scan8_index, int above, int32_t *out) {
     out[0] = n.scan8_index; out[1] = n.in_left_mb; out[2] = n.in_up_mb;
 }
 
+}  // extern "C"
+namespace {
+// ---- a real stream through the build's syntax parser (avr_h264.h) and one of the recorders, on the CPU: the K2 records of
+// every slice (compress side, with the payload each slice was offered), or the K1 records (decompress side, the bins answered
+// from `recoded`, the per-slice recoded bytes the test made from those K2 records with the oracle).  residual = fire all eleven hooks.
+struct stream_args {
+    const uint8_t *file; size_t len; int residual, decompress; const uint8_t *recoded; const uint64_t *recoded_off;
+    uint16_t *recs; size_t recs_cap; uint64_t *rec_end; size_t slice_cap; uint64_t *n_slices;
+    uint8_t *payloads; size_t pay_cap; uint64_t *pay_end; uint8_t *first_states; int32_t *n_states;
+    uint8_t *offered; size_t offered_cap; uint64_t *n_offered;      // compress: out (1 = hooked); decompress: in
+};
+static void attach(cpu_compress_driver &drv, stream_decoder *d) { drv.decoder = d; }
+static void attach(cpu_decompress_driver &, stream_decoder *) {}
+template <class Driver>
+static void stream_through(Driver &drv, stream_args *a) {
+    hooks h = hook_adapter<Driver>::make(&drv);
+    avr::h264::h264_stream_decoder dec;
+    dec.residual_hooks = a->residual != 0;
+    attach(drv, &dec);
+    struct reader { const uint8_t *p; size_t n, at; } r{a->file, a->len, 0};
+    dec.decode_video(&h, [](void *o, uint8_t *b, int n) {
+        reader *r = static_cast<reader *>(o);
+        const size_t k = std::min<size_t>(size_t(n), r->n - r->at);
+        memcpy(b, r->p + r->at, k);
+        r->at += k;
+        return int(k); }, &r);
+    drv.cabac_contexts.clear();
+    if (drv.recs.size() > a->recs_cap || drv.rec_end.size() > a->slice_cap) throw std::runtime_error("stream_through: output arrays too small");
+    std::copy(drv.recs.begin(), drv.recs.end(), a->recs);
+    std::copy(drv.rec_end.begin(), drv.rec_end.end(), a->rec_end);
+    *a->n_slices = drv.rec_end.size();
+}
+static int stream_run(void *p) {
+    stream_args *a = static_cast<stream_args *>(p);
+    if (a->decompress) {
+        cpu_decompress_driver drv;
+        drv.recoded = a->recoded; drv.recoded_off = a->recoded_off;
+        drv.offered = a->offered; drv.n_offered = size_t(*a->n_offered);
+        stream_through(drv, a);
+        std::copy(drv.first_states.begin(), drv.first_states.end(), a->first_states);
+        std::copy(drv.n_states.begin(), drv.n_states.end(), a->n_states);
+    } else {
+        cpu_compress_driver drv;
+        stream_through(drv, a);
+        if (drv.payloads.size() > a->pay_cap) throw std::runtime_error("stream_through: payload array too small");
+        std::copy(drv.payloads.begin(), drv.payloads.end(), a->payloads);
+        std::copy(drv.payload_end.begin(), drv.payload_end.end(), a->pay_end);
+        if (drv.offered.size() > a->offered_cap) throw std::runtime_error("stream_through: offered array too small");
+        std::copy(drv.offered.begin(), drv.offered.end(), a->offered);
+        *a->n_offered = drv.offered.size();
+    }
+    return 0;
+}
+}  // namespace
+extern "C" {
+
 // ---- the reference's roundtrip (recode.cpp:1601-1640) over a file with recorded slices; GPU.
 // Returns 0 when the reconstruction is byte-identical, 1 when not, -1 on an exception (message in err).
 struct rt_args {
@@ -432,6 +515,14 @@ static int rtb_run(void *p) {
     a->stats[1] = bins[0] == bins[1];
     a->stats[2] = compressed.size();
     return rc;
+}
+int t_stream_records(const uint8_t *file, size_t len, int residual, int decompress, const uint8_t *recoded, const uint64_t *recoded_off,
+                     uint16_t *recs, size_t recs_cap, uint64_t *rec_end, size_t slice_cap, uint64_t *n_slices, uint8_t *payloads, size_t pay_cap,
+                     uint64_t *pay_end, uint8_t *first_states, int32_t *n_states, uint8_t *offered, size_t offered_cap, uint64_t *n_offered,
+                     char *err, size_t err_cap) {
+    stream_args a{file, len, residual, decompress, recoded, recoded_off, recs, recs_cap, rec_end, slice_cap, n_slices, payloads, pay_cap, pay_end,
+                  first_states, n_states, offered, offered_cap, n_offered};
+    return guarded(stream_run, &a, err, err_cap);
 }
 int t_roundtrip_blocks(const uint8_t *file, size_t file_len, size_t n_slices, const uint64_t *offset, const uint64_t *size,
                        const int32_t *spec, const uint64_t *block_off, const int32_t *blocks, const uint8_t *init_states,

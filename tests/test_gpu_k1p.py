@@ -367,10 +367,15 @@ def test_chunked_census_sample_second_pass_and_validation(avr, oracle, stride, h
 
 # ------------------------------------------------------------------ K2p: the recoded range coder in three passes
 
-def test_range_chunked_random_and_extremes(avr, oracle):
+@pytest.mark.parametrize("seg_len", [0, 1, 3])
+def test_range_chunked_random_and_extremes(avr, oracle, hooks, seg_len):
     """avr_range_encode_chunked_device against the oracle: ragged lengths around the chunk size, adaptive and fixed
-    estimators, certain bins (no output for thousands of bins), the most lopsided estimators, empty slices, and a
-    zero-probability bin in the middle of a slice (status, like arithmetic_code.h:116-118)."""
+    estimators, certain bins (no output for thousands of bins), the most lopsided estimators, empty slices, a record with
+    neg 0 (the range collapses to a few bits: the double-precision walk hands the slice to the integer one), and a
+    zero-probability bin in the middle of a slice (status, like arithmetic_code.h:116-118).  seg_len 1 / 3 (test hook): the
+    passes run segment by segment on two streams, as they do for long slices, with a segment boundary at every (third) chunk."""
+    if seg_len:
+        hooks(k2p_seg_len=seg_len)
     rng = np.random.default_rng(17)
     def rec(b, pos, neg):
         return b | (pos << 1) | (neg << 8)
@@ -378,6 +383,9 @@ def test_range_chunked_random_and_extremes(avr, oracle):
               for i, n in enumerate([0, 1, 7, 8, 9, 1023, 1024, 1025, 2047, 2048, 4097, 30000, 12345, 50000, 3, 20000])]
     slices += [np.array([rec(1, 0x5f, 1)] * 9000, np.uint16), np.array([rec(0, 0x5f, 1)] * 5000, np.uint16),
                np.array([rec(1, 9, 0)] * 6000 + [rec(0, 1, 1)] * 40, np.uint16), np.array([rec(i & 1, 1, 1) for i in range(7000)], np.uint16)]
+    collapse = oracle_lib.random_range_stream(rng, 9000)
+    collapse[4321] = np.uint16(rec(0, 77, 0))                # bin 0 with neg 0: the new range is range mod 77
+    slices.append(collapse)
     zero = oracle_lib.random_range_stream(rng, 5000)
     zero[2500] = np.uint16(1 | (0 << 1) | (9 << 8))
     slices.append(zero)
@@ -388,6 +396,15 @@ def test_range_chunked_random_and_extremes(avr, oracle):
         want, st = oracle.range_encode(r)
         assert st == 0 and status[i] == 0 and got[i] == want, f"slice {i} n={len(r)}"
     assert status[-1] == avr.SLICE_ZERO_PROB and oracle.range_encode(zero)[1] == 1
+    # the same slices through the batch API (which picks the three-pass form by the batch's shape: force it)
+    hooks(k2p_seg_len=seg_len, k1_path=2)
+    with avr.Batch(0, len(slices), sum(len(r) for r in slices) + 8) as b:
+        for r in slices:
+            b.add_slice_range(r)
+        b.run()
+        for i, r in enumerate(slices[:-1]):
+            assert b.get(i) == (got[i], 0), f"slice {i}"
+        assert b.get(len(slices) - 1)[1] == avr.SLICE_ZERO_PROB
 
 
 def test_range_chunked_config2_cut_equals_the_serial_kernel(avr, oracle):
@@ -403,3 +420,58 @@ def test_range_chunked_config2_cut_equals_the_serial_kernel(avr, oracle):
     for s in (0, 11, 23):
         cfg, nbh, off, recs, _ = host_synth(avr, 2, 1, avr.KIND_RANGE, 1000, first=s)
         assert chunked[s] == oracle.range_encode(recs[:int(nbh[0])])[0]
+
+
+@pytest.mark.parametrize("workload,n_slices", [(2, 512), (3, 4096), (4, 16384)])
+def test_range_chunked_full_size(avr, oracle, workload, n_slices):
+    """The compress direction (K2, three-pass form) at the full size of BASELINE.json configs[1], [2] and [3] under the
+    driver: every status 0, the same bytes on a second run, byte equality with the oracle on a seeded sample of slices (the
+    longest and the shortest among them) with the reference decoder's round trip, and -- config 2, where the whole batch is
+    310 M bins -- every one of the 512 slices against the threaded oracle through a checksum of checksums."""
+    w = avr.DeviceWorkload.synth(workload, n_slices, avr.KIND_RANGE, 0, 1000)
+    w.encode_chunked()
+    got, status = w.results()
+    assert not any(status)
+    w.out.zero_()
+    w.encode_chunked()
+    again, _ = w.results()
+    assert again == got
+    nb = w.n_bins.cpu().numpy()
+    sample = sorted(set(np.random.default_rng(100 + workload).integers(0, n_slices, 20).tolist() + [0, n_slices - 1, int(nb.argmax()), int(nb.argmin())]))
+    for k, s in enumerate(sample):
+        cfg, nbh, off, recs, _ = host_synth(avr, workload, 1, avr.KIND_RANGE, 1000, first=s)
+        assert int(nbh[0]) == int(nb[s])
+        r = recs[:int(nbh[0])]
+        want, st = oracle.range_encode(r)
+        assert st == 0 and got[s] == want, f"slice {s}"
+        if k < 4:
+            assert np.array_equal(oracle.range_decode(got[s], r), r & 1)         # encode -> decode round trip (arithmetic_code.h:218-288)
+    if workload == 2:
+        import hashlib
+        cfg, nbh, off, recs, _ = host_synth(avr, workload, n_slices, avr.KIND_RANGE, 1000)
+        parts = [recs[int(off[i]):int(off[i]) + int(nbh[i])] for i in range(n_slices)]
+        roff = np.zeros(n_slices + 1, np.uint64)
+        roff[1:] = np.cumsum(nbh.astype(np.uint64))
+        want, st = oracle.encode_batch(avr.KIND_RANGE, np.concatenate(parts), roff, None, 0, threads=16)
+        assert not st.any()
+        dig = lambda chunks: hashlib.sha256(b"".join(hashlib.sha256(c).digest() for c in chunks)).hexdigest()
+        assert dig(got) == dig(want)
+    assert 0.9 < w.total_bins / (8 * sum(len(x) for x in got)) < 1.8
+
+
+def test_range_chunked_short_region_is_an_overflow_not_a_spill(avr, oracle):
+    """A slice whose output region is too small for the byte sums of passes 2 and 3 comes back AVR_SLICE_OVERFLOW and its
+    neighbours' bytes are the oracle's: the sums of one slice never spill into the next one's (k_k2p_fits)."""
+    rng = np.random.default_rng(5)
+    slices = [oracle_lib.random_range_stream(rng, 20000) for _ in range(5)]
+    w = avr.DeviceWorkload.from_host(1, slices, None, 0)
+    # slice 2's region cut to a few bytes: rebuild out_off with the same total
+    import torch
+    off = w.out_off.cpu().numpy().astype(np.int64)
+    off[3:] -= int(off[3] - off[2]) - 64
+    w.out_off.copy_(torch.from_numpy(off))
+    w.encode_chunked()
+    got, status = w.results()
+    assert status[2] == avr.SLICE_OVERFLOW
+    for i in (0, 1, 3, 4):
+        assert status[i] == 0 and got[i] == oracle.range_encode(slices[i])[0], f"slice {i}"

@@ -291,6 +291,31 @@ def test_full_size_properties(avr, oracle, workload, n_slices):
     assert 0.9 < w.total_bins / (8 * total) < 1.8
 
 
+@pytest.mark.parametrize("n_slices", [65536, 1048576])
+def test_full_size_properties_compress_direction(avr, oracle, n_slices):
+    """Config 5 at its own size (and a 64Ki-slice cut) through K2, the recoded range coder, one lane per slice: statuses,
+    idempotence, sampled byte equality with the oracle and the reference decoder's round trip, and a checksum of checksums over
+    every slice against the threaded oracle."""
+    w = avr.DeviceWorkload.synth(5, n_slices, avr.KIND_RANGE, 0, 1000)
+    w.encode()
+    got, status = w.results()
+    assert not any(status)
+    w.out.zero_()
+    w.encode()
+    again, _ = w.results()
+    assert again == got
+    for s in sorted(set(np.random.default_rng(19).integers(0, n_slices, 6).tolist() + [0, n_slices - 1])):
+        cfg, nb, off, recs, _ = host_synth(avr, 5, 1, avr.KIND_RANGE, 1000, first=s)
+        r = recs[:int(nb[0])]
+        want, st = oracle.range_encode(r)
+        assert st == 0 and got[s] == want, f"slice {s}"
+        assert np.array_equal(oracle.range_decode(got[s], r), r & 1)
+    cfg, nb, off, recs, _ = host_synth(avr, 5, n_slices, avr.KIND_RANGE, 1000)
+    want, st = oracle.encode_batch(avr.KIND_RANGE, *compact(recs, off, nb), None, 0, threads=16)
+    assert not st.any()
+    assert digest(got) == digest(want)
+
+
 def test_one_batch_over_several_devices(avr, oracle):
     """avr_multi_*: one batch sharded by greedy LPT over a device list (here the same GPU named three times: three
     sub-batches, each with its own host thread, stream and staging), results gathered by slice index."""

@@ -19,7 +19,7 @@ P = oracle_lib.ptr
 
 @pytest.fixture(scope="module")
 def host(avr):
-    deps = [SRC, os.path.join(CSRC, "host", "avr_host.h"), os.path.join(CSRC, "host", "avr_recode.h"), avr.LIB_PATH]
+    deps = [SRC, avr.LIB_PATH] + [os.path.join(CSRC, "host", f) for f in ("avr_host.h", "avr_recode.h", "avr_model.h", "avr_h264.h", "avr_h264_tables.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-I/opt/rocm/include",
                         "-D__HIP_PLATFORM_AMD__", "-o", SO, SRC, "-L" + os.path.dirname(avr.LIB_PATH), "-lavrecode_hip",

@@ -8,6 +8,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent("""
@@ -113,3 +115,35 @@ def test_lpt_and_balanced_ranges_small_cases():
     assert balanced_ranges([], 2) == [0, 0, 0]
     b = balanced_ranges([3] * 10, 4)
     assert b[0] == 0 and b[-1] == 10 and all(x <= y for x, y in zip(b, b[1:]))
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_hip_path_code_what_one_rank_codes(tmp_path):
+    """The N > 1 launch the driver uses -- torch.distributed.run, one process per rank -- on the HIP path, rehearsed on the
+    one GPU of the test box: `bench.py --gpus 2 --backend gloo --scaling strong` as a FRESH child process (both ranks on GPU 0,
+    gloo for the measurement's barrier and reductions; on a multi-GPU node the backend is RCCL and each rank has its own
+    device, same code otherwise).  One batch of 2048 slices of config 4 is split over the two ranks by bins; the bytes the two
+    ranks code must add up to what a single rank codes for the same 2048 slices, with no slice in error.  A rehearsal of the
+    launch, the sharding and the reductions -- not a scaling measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--workload", "4", "--slices", "2048", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True,
+                         env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    single = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29671", os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", "strong"]
+                         + common, capture_output=True, text=True, env=env, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["slice_status_errors"] == 0
+    assert line["config"]["batch_slices"] == 2048 and 0 < line["config"]["slices_per_gpu"] < 2048
+    assert line["config"]["h264_bytes_all_gpus"] == single["config"]["h264_bytes_per_gpu"]        # the shards are the batch
+    out = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out):                                   # kept for profiles/ (tools/collect_profiles.py)
+        with open(os.path.join(out, "rehearsal_2ranks_w4.json"), "w") as f:
+            f.write(json.dumps(line) + "\n")
