@@ -10,13 +10,18 @@
 //                                           compressor commits to it: payload_decodes())
 //
 // Supported: frame pictures (no field / MBAFF coding), I / P / B slices, one slice group, 4:2:0 / 4:2:2 / 4:4:4
-// (not separate planes), 8x8 transform, cabac_init_idc 0 (see avr_h264_tables.h for why), no I_PCM.  Anything
-// else is reported as "not hooked": the slice's bytes stay in the literal stream of the container, exactly as the
-// reference treats a slice whose payload it cannot find (recode.cpp:1146-1152).
+// (not separate planes), 8x8 transform, cabac_init_idc 0 (verified on real streams) and 1 / 2 (tables unverified, see
+// avr_h264_tables.h).  Not supported, by design: field / MBAFF pictures, slice groups, and I_PCM macroblocks -- an I_PCM sends
+// raw samples through the decoder's skip_bytes hook, which the reference itself answers with an exception
+// (recode.cpp:168-170, "CABAC decoder doesn't use skip_bytes"): where the reference gives up on the whole file, this build
+// leaves the one slice literal.  Anything unsupported is reported as "not hooked": the slice's bytes stay in the literal
+// stream of the container, exactly as the reference treats a slice whose payload it cannot find (recode.cpp:1146-1152);
+// `recode probe` counts such slices per reason.
 #pragma once
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -271,7 +276,6 @@ inline slice_header parse_slice_header(const std::vector<uint8_t> &rbsp, int nal
     h.chroma_array_type = sps.chroma_format_idc;
     h.transform_8x8_mode = pps.transform_8x8_mode;
     h.direct_8x8_inference = sps.direct_8x8_inference;
-    if (h.type != SLICE_I && h.cabac_init_idc != 0) throw unsupported("cabac_init_idc 1 / 2 (initialisation columns not reproduced, avr_h264_tables.h)");
     if (int64_t(h.first_mb) >= int64_t(h.width_mbs) * h.height_mbs) throw bad_stream("first_mb_in_slice outside the picture");
     return h;
 }
@@ -345,7 +349,7 @@ class slice_parser {
     // mb_info per macroblock of the picture, kept across the slices of a picture; slice_no: a number unique per slice
     slice_parser(Bins &bins, const slice_header &h, uint8_t *states, std::vector<mb_info> &mbs, int slice_no, model_hooks model)
         : b_(bins), h_(h), st_(states), mbs_(mbs), slice_no_(slice_no), model_(model) {
-        for (int c = 0; c < 1024; c++) st_[c] = init_state(c, h.type == SLICE_I, h.qp);
+        for (int c = 0; c < 1024; c++) st_[c] = init_state(c, h.type == SLICE_I, h.qp, h.cabac_init_idc);
         const int cat = h.chroma_array_type;
         chroma_w_ = cat == 3 ? 4 : cat == 0 ? 0 : 2;     // chroma plane size in 4x4 blocks
         chroma_h_ = cat == 3 ? 4 : cat == 2 ? 4 : cat == 0 ? 0 : 2;
@@ -901,7 +905,11 @@ inline bool mp4_nals(const std::vector<uint8_t> &d, std::vector<nal_ref> *out) {
 // slice, its bins are requested one by one in syntax order.
 class h264_stream_decoder : public host::stream_decoder {
   public:
-    struct stats_t { size_t slices = 0, hooked = 0, unsupported = 0, failed = 0, macroblocks = 0; std::string last_reason; } stats;
+    struct stats_t {
+        size_t slices = 0, hooked = 0, unsupported = 0, failed = 0, macroblocks = 0;
+        std::string last_reason;
+        std::map<std::string, size_t> literal_reasons;   // why slices were left literal: the message of what stopped the parser, counted
+    } stats;
     // Fire begin / end_sub_mb and begin / end_coding_type around residual blocks (model_hooks::residual): all eleven hooks of
     // recode.cpp:219-235 are then live, h264_model keys significance-map bins by position and nonzero count, and the
     // recorders queue them behind the block's nonzero count.  Off by default, as in the reference's fork ("Not called").
@@ -946,6 +954,7 @@ class h264_stream_decoder : public host::stream_decoder {
             return ends_cleanly(bins.d.bit_position(), offered_payload_, offered_size_);
         } catch (const std::exception &e) {
             stats.last_reason = e.what();
+            stats.literal_reasons[e.what()]++;
             return false;
         }
     }
@@ -970,8 +979,8 @@ class h264_stream_decoder : public host::stream_decoder {
             sh = parse_slice_header(rbsp, type, ref_idc, sps_, pps_);
             if (sh.data_offset >= rbsp.size()) throw bad_stream("slice without data");
             sh.x264_old_444_cbf = sh.chroma_array_type == 3 && x264_build_ >= 0 && x264_build_ < 151;
-        } catch (const unsupported &e) { stats.unsupported++; stats.last_reason = e.what(); return; }
-        catch (const bad_stream &e) { stats.failed++; stats.last_reason = e.what(); return; }
+        } catch (const unsupported &e) { stats.unsupported++; stats.last_reason = e.what(); stats.literal_reasons[e.what()]++; return; }
+        catch (const bad_stream &e) { stats.failed++; stats.last_reason = e.what(); stats.literal_reasons[std::string("header: ") + e.what()]++; return; }
         // What frame_spec is told (recode.cpp:173): a number that is the same for the slices of a picture and differs from one
         // picture to the next.  frame_num itself repeats across a non-reference picture and the one after it, and h264_model
         // clears its per-picture store only when the number changes (update_frame_spec, recode.cpp:831-850): with the residual

@@ -8,7 +8,8 @@
 // slices of a file in one GPU batch (K2 on the way in, K3 on the CPU + K1 on the way out).
 //
 // One more command, `recode probe <input>`: parse every slice with the build's own CABAC engine and report how many
-// parse to their end (no GPU, nothing written) -- what tests/test_h264.py pins the parser and its tables with.
+// parse to their end, and for the others why not, counted per reason (no GPU, nothing written) -- what tests/test_h264.py
+// pins the parser and its tables with, and what shows on any file how much of it the parser leaves literal.
 //
 // Environment: AVR_DEVICE = HIP device index (default 0); AVR_MODEL_HOOKS=1 = the stream decoder also fires begin / end_sub_mb
 // and begin / end_coding_type around residual blocks (all eleven hooks of recode.cpp:219-235 live: the significance-map side of
@@ -179,7 +180,15 @@ int probe(const std::string &input_filename) {
         r->at += k;
         return int(k); }, &r);
     std::cout << "{\"slices\": " << dec.stats.slices << ", \"parse_to_the_end\": " << c.ok << ", \"fail\": " << c.bad << ", \"unsupported\": "
-              << dec.stats.unsupported << ", \"header_failures\": " << dec.stats.failed << "}" << std::endl;
+              << dec.stats.unsupported << ", \"header_failures\": " << dec.stats.failed << ", \"literal_reasons\": {";
+    bool first = true;                                                // why slices would stay literal blocks, counted per reason
+    for (const auto &kv : dec.stats.literal_reasons) {
+        std::string key;
+        for (char ch : kv.first) { if (ch == '"' || ch == '\\') key += '\\'; key += ch; }
+        std::cout << (first ? "" : ", ") << "\"" << key << "\": " << kv.second;
+        first = false;
+    }
+    std::cout << "}}" << std::endl;
     if (c.bad || dec.stats.unsupported || dec.stats.failed) std::cerr << "last reason: " << (c.why.empty() ? dec.stats.last_reason : c.why) << std::endl;
     return 0;
 }

@@ -41,7 +41,8 @@ def test_every_slice_of_the_real_streams_parses_to_its_end(recode, name):
     out = subprocess.run([recode, "probe", clip(name)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     res = json.loads(out.stdout)
-    assert res == {"slices": CLIPS[name][0], "parse_to_the_end": CLIPS[name][0], "fail": 0, "unsupported": 0, "header_failures": 0}, out.stderr
+    assert res == {"slices": CLIPS[name][0], "parse_to_the_end": CLIPS[name][0], "fail": 0, "unsupported": 0, "header_failures": 0,
+                   "literal_reasons": {}}, out.stderr
 
 
 def _stream_records(host, data, residual, decompress, recoded=None, offered=None):
@@ -142,13 +143,17 @@ def test_cli_surface(recode, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("all_hooks", [0, 1])
 @pytest.mark.parametrize("name", sorted(CLIPS))
-def test_roundtrip_of_a_real_file(recode, tmp_path, name):
+def test_roundtrip_of_a_real_file(recode, tmp_path, name, all_hooks):
     """BASELINE.json configs[0] (`./recode roundtrip <clip>`, README.md:24) on the clips this image has: compress (syntax parser
-    -> eleven hooks -> K2 on the GPU), decompress (K3 on the CPU, K1 on the GPU from resolved codes), byte-compare."""
+    -> eleven hooks -> K2 on the GPU), decompress (K3 on the CPU, K1 on the GPU from resolved codes), byte-compare.
+    all_hooks = 1 (AVR_MODEL_HOOKS=1): begin / end_sub_mb and begin / end_coding_type fire too -- h264_model's significance-map
+    keys, the recorders' queueing and the nonzero counts sent ahead are live on the product path (rows a13 / f3)."""
     src = clip(name)
     comp = tmp_path / (name + ".recode")
-    out = subprocess.run([recode, "roundtrip", src, str(comp)], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, AVR_MODEL_HOOKS=str(all_hooks))
+    out = subprocess.run([recode, "roundtrip", src, str(comp)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr
     assert "Compress-decompress roundtrip succeeded:" in out.stderr
     # With frame_spec / mb_xy the only model hooks firing (what the reference's source says of its FFmpeg fork, recode.cpp:173-215)
@@ -157,7 +162,7 @@ def test_roundtrip_of_a_real_file(recode, tmp_path, name):
     assert 90.0 < ratio < 102.0, out.stderr
     # the two halves on their own, through files
     back = tmp_path / (name + ".back")
-    assert subprocess.run([recode, "decompress", str(comp), str(back)], timeout=600).returncode == 0
+    assert subprocess.run([recode, "decompress", str(comp), str(back)], timeout=600, env=env).returncode == 0
     assert back.read_bytes() == open(src, "rb").read()
     # the container holds one coded block per slice the compressor could place (unescaped payloads are found in the file)
     import avrecode_ms_amd  # noqa: F401  (path set-up)

@@ -118,6 +118,7 @@ def test_crafted_headers_are_rejected_not_dereferenced(recode_asan, tmp_path, ca
     # no slice of these parses; a slice whose header is in range (the last of "just past the picture") fails in its payload
     assert res["parse_to_the_end"] == 0 and res["header_failures"] >= 1 and res["header_failures"] + res["fail"] >= res["slices"], probe.stdout
     assert "AddressSanitizer" not in probe.stderr and "runtime error" not in probe.stderr, probe.stderr[-2000:]
+    assert sum(res["literal_reasons"].values()) >= res["slices"] and any(k.startswith("header: ") for k in res["literal_reasons"]), probe.stdout
     # and the file still round-trips: what does not parse stays literal (no GPU needed: there is nothing to code)
     comp, back = tmp_path / "c.recode", tmp_path / "back.h264"
     for cmd in ([recode_asan, "compress", str(src), str(comp)], [recode_asan, "decompress", str(comp), str(back)]):
