@@ -94,7 +94,7 @@ def build_recode(force: bool = False, verbose: bool = False) -> str:
         if os.path.exists(RECODE_PATH):
             return RECODE_PATH
         raise AvrError("no C++ compiler and no prebuilt recode binary")
-    cmd = [cxx, "-O2", "-std=c++17", "-I" + _CSRC, "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", RECODE_PATH + ".tmp",
+    cmd = [cxx, "-O2", "-pthread", "-std=c++17", "-I" + _CSRC, "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", RECODE_PATH + ".tmp",
            os.path.join(_HOST, "recode_main.cpp"), "-L" + _HERE, "-lavrecode_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))

@@ -189,10 +189,13 @@ int avr_test_hook_set(const char *name, uint32_t value) {
     else if (!strcmp(name, "census_stride")) h.census_stride = value;
     else if (!strcmp(name, "chain_lanes")) h.chain_lanes = value;
     else if (!strcmp(name, "k1_form_norm")) h.k1_form_norm = value;
+    else if (!strcmp(name, "k1_emit_lds")) h.k1_emit_lds = value;
     else if (!strcmp(name, "k1_path")) h.k1_path = value;
     else if (!strcmp(name, "no_dense")) h.no_dense = value;
     else if (!strcmp(name, "no_hint")) h.no_hint = value;
     else if (!strcmp(name, "k2p_seg_len")) h.k2p_seg_len = value;
+    else if (!strcmp(name, "chain_whole")) h.chain_whole = value;
+    else if (!strcmp(name, "chain_force_redo")) h.chain_force_redo = value;
     else if (!strcmp(name, "reset")) h = avr::TestHooks{};
     else return fail(AVR_ERR_INVALID, "unknown test hook %s", name);
     return AVR_OK;

@@ -37,7 +37,10 @@ struct TestHooks {
     uint32_t census_stride;          // sampling stride of both census kernels (0 = the built-in 16)
     uint32_t chain_lanes;            // lanes per wave of k_k1p_ctxchain (0 = by batch shape)
     uint32_t k1_form_norm;           // one-lane-per-slice K1 in normalised form (CabacLaneN)
+    uint32_t k1_emit_lds;            // one-lane-per-slice K1 with its digits staged in LDS and stored in 16-byte rows (CabacLaneS)
     uint32_t k1_path, no_dense, no_hint;   // the environment switches above, settable per test (non-zero wins over env())
+    uint32_t chain_whole;            // K1p: every context chain start to end (k_k1p_ctxchain alone), no segments
+    uint32_t chain_force_redo;       // K1p: the segmented chains hand every n-th (slice, context) pair to the whole-slice walk
     uint32_t k2p_seg_len;            // chunks per segment of K2p's overlapped passes (0 = by batch shape): short slices through many segments
 };
 #ifdef AVR_TEST_HOOKS

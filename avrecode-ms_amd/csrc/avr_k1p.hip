@@ -447,6 +447,215 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
     if (final_states) final_states[size_t(s) * p.ns_full + col] = uint8_t(st);
 }
 
+// ------------------------------------------------------------------ the chains in segments
+//
+// k_k1p_ctxchain's time is its longest lane: the hottest context of the longest slice, 600 chunks in a row with about seven
+// dependent look-ups each (0.29 of config 2's 1.7 ms).  What cuts a chain is that the state machine is MONOTONE: order the 126
+// states by the probability they give a 1 -- (valMPS 0, pStateIdx 62) first, (valMPS 1, pStateIdx 62) last -- and the state
+// after a bin never overtakes: s <= s' implies T(s, b) <= T(s', b) for either bin value (an MPS moves every state one step
+// towards its own end, an LPS moves it back by transIdxLPS, which is non-decreasing in pStateIdx: cabac_code.h:43-47 with
+// ITU-T H.264 Table 9-45; tests/test_k1p_emul.py walks all pairs).  So when the walks from the two extreme states have met,
+// every state in between has met them too, and from there on the context's state does not depend on where the segment was
+// entered.  Each (slice, context) chain is cut into kChainSegs segments of equal chunk counts:
+//   k_k1p_chain_seg   lane per (slice, context, segment): both extreme states through the segment's chunks, side by side (two
+//                     independent look-up chains in flight); from the chunk where they have met, the state of every chunk is
+//                     noted in `est` as final.  Summary: exit state, the chunk they met at -- and, for the segments they do NOT
+//                     meet in, which are the ones with few bins, those bins themselves (up to kSegBits of them, as a bit string:
+//                     a run of one value needs about 80 bins for the walks to meet, 18 LPS steps down and 62 MPS steps up).
+//   k_k1p_chain_fix   lane per (slice, context, segment): the segment's true entry state -- the exit of the nearest earlier
+//                     segment whose walks met (or the slice's initial state), taken through the bit strings of the segments
+//                     between -- and from it the chunks before the meeting point once more, this time for `est`.  A segment in
+//                     between with more than kSegBits bins whose walks did not meet (nothing forbids it) is simply walked again,
+//                     chunk by chunk, by the lanes that need its exit state.
+// Batches of short slices (a segment would be a chunk or two) keep k_k1p_ctxchain, the start-to-end walk.
+constexpr uint32_t kChainSegs = 8, kSegWaves = 16;               // 16 waves share the 64 KiB look-up table: two such workgroups per CU
+constexpr uint32_t kSegBits = 128;                               // bins a segment's bit string holds
+struct alignas(16) SegSummary {
+    uint64_t bits[2];         // the segment's bins of this context, first bin in bit 0 of bits[0] (valid when n_bins <= kSegBits)
+    uint32_t n_bins;
+    uint8_t exit_state;       // state after the segment when the walks met
+    uint8_t met;              // 1: the walks met (exit_state valid, chunks from met_chunk on are noted)
+    uint16_t met_chunk;       // first chunk of the segment (relative to its start) whose entry state is noted; segment length if none
+};
+
+// One chunk's step of a context's chain for NS states at once: the context's bins of the chunk are bits [pos, end) of the chunk's
+// bit string (window w: 128 bits from dword pos / 32), taken eight per look-up.  Same structure as k_k1p_ctxchain's step.
+template <int NS>
+__device__ __forceinline__ void chain_step(const uint8_t *tn, const uint32_t *bw_cur, uint32_t pos, uint32_t end, const uint4 &w0, uint32_t (&st)[NS]) {
+    uint32_t left = end > pos ? end - pos : 0u;
+    const uint32_t sh = pos & 31u;
+    auto four = [&](uint32_t avail) {
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t n = left < 8u ? left : 8u;
+            uint32_t off = (128u << n) - 128u + (avail & ((1u << n) - 1u));
+            asm volatile("" : "+v"(off));
+#pragma unroll
+            for (int q = 0; q < NS; q++) st[q] = tn[(st[q] << n) + off];
+            avail >>= 8;
+            left -= n;
+        }
+    };
+    four(__builtin_amdgcn_alignbit(w0.y, w0.x, sh));
+    if (__any(left != 0)) {
+        four(__builtin_amdgcn_alignbit(w0.z, w0.y, sh));
+        if (__any(left != 0)) {
+            pos += 64;
+            uint32_t avail = __builtin_amdgcn_alignbit(w0.w, w0.z, sh);
+            uint32_t have = 32;
+            while (left) {
+                if (have == 0) {
+                    const uint32_t wi = (pos >> 5) & 31u;
+                    avail = __builtin_amdgcn_alignbit(bw_cur[wi + 1], bw_cur[wi], pos & 31u);
+                    have = 32;
+                }
+                const uint32_t n = left < 8u ? left : 8u;
+                uint32_t off = (128u << n) - 128u + (avail & ((1u << n) - 1u));
+                asm volatile("" : "+v"(off));
+#pragma unroll
+                for (int q = 0; q < NS; q++) st[q] = tn[(st[q] << n) + off];
+                avail >>= 8;
+                left -= n; pos += n; have -= 8;
+            }
+        }
+    }
+}
+
+// Which (slice, context, segment) a lane of the two kernels below has; false: none.
+struct ChainLane { uint32_t s, k, seg, c_begin, c_end, nc, col; };
+__device__ __forceinline__ bool chain_lane(const Plan &p, uint32_t n_slices, uint32_t groups, uint32_t chain_lanes, const int32_t *status, ChainLane *o) {
+    const uint32_t wave = blockIdx.x * kSegWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t seg = wave % kChainSegs, sg = wave / kChainSegs;
+    const uint32_t s = sg / groups, k = (sg - s * groups) + lane * groups, nk = p.n_states;
+    if (lane >= chain_lanes || s >= n_slices || status[s] != AVR_SLICE_OK || k >= nk) return false;
+    const uint32_t col = p.index[k];
+    if (col >= p.ns_full) return false;
+    const uint32_t nc = (p.n_bins[s] + kChunk - 1) / kChunk, seg_len = (nc + kChainSegs - 1) / kChainSegs;
+    const uint32_t c_begin = seg * seg_len < nc ? seg * seg_len : nc, c_end = c_begin + seg_len < nc ? c_begin + seg_len : nc;
+    *o = ChainLane{s, k, seg, c_begin, c_end, nc, col};
+    return true;
+}
+
+__global__ __launch_bounds__(64 * kSegWaves) void k_k1p_chain_seg(Plan p, uint32_t n_slices, uint32_t groups, uint32_t chain_lanes, const int32_t *status,
+                                                       const uint8_t *tng, const uint32_t *lbits, const uint16_t *lend, uint8_t *est, SegSummary *summ) {
+    __shared__ uint8_t tn[kTnBytes];
+    for (uint32_t i = threadIdx.x; i < kTnBytes / 16; i += 64 * kSegWaves) reinterpret_cast<uint4 *>(tn)[i] = reinterpret_cast<const uint4 *>(tng)[i];
+    __syncthreads();
+    ChainLane L;
+    if (!chain_lane(p, n_slices, groups, chain_lanes, status, &L)) return;
+    const uint32_t nk = p.n_states, row4 = ((nk + 3) >> 2) << 2, k = L.k;
+    const uint32_t c0 = p.chunk_base[L.s] + L.c_begin, n_ch = L.c_end - L.c_begin;
+    const uint16_t *le = lend + size_t(c0) * nk + k;
+    const uint32_t *bw_ahead = lbits + size_t(c0) * 32, *bw_cur = bw_ahead;
+    uint8_t *eo = est + size_t(c0) * row4 + k;
+    auto ends = [&]() { const uint32_t e1 = le[0], em = le[-1]; le += nk; return make_uint2(k ? em : 0u, e1); };
+    auto window = [&](const uint32_t *bw, uint32_t pos) { const uint32_t wi = (pos >> 5) & 31u; return make_uint4(bw[wi], bw[wi + 1], bw[wi + 2], bw[wi + 3]); };
+    uint2 e0 = ends(), e1 = ends(), e2 = ends(), e3 = ends();
+    uint4 w0 = window(bw_ahead, e0.x), w1 = window(bw_ahead + 32, e1.x);
+    bw_ahead += 64;
+    uint32_t st[2] = {124u, 125u};                               // the two ends of the order: (valMPS 0, pStateIdx 62), (valMPS 1, pStateIdx 62)
+    uint32_t met_chunk = n_ch, n_bins = 0;
+    uint64_t bits0 = 0, bits1 = 0;
+    for (uint32_t c = 0; c < n_ch; c++) {
+        const uint2 e4 = ends();
+        const uint4 w2 = window(bw_ahead, e2.x);
+        bw_ahead += 32;
+        if (st[0] == st[1]) {                                    // met: this chunk's entry state is what it is whatever the segment was entered in
+            *eo = uint8_t(st[0]);
+            met_chunk = met_chunk < c ? met_chunk : c;
+        }
+        eo += row4;
+        const uint32_t pos = e0.x, end = e0.y, cnt = end > pos ? end - pos : 0u;
+        if (n_bins < kSegBits && cnt) {                          // the bins themselves, while they fit: what a segment without a meeting point is carried on by
+            const uint32_t sh = pos & 31u;                       // (up to 64 of a chunk's: with more than that the string is full soon anyway, and then unused)
+            const uint64_t lo = uint64_t(__builtin_amdgcn_alignbit(w0.y, w0.x, sh)) | uint64_t(__builtin_amdgcn_alignbit(w0.z, w0.y, sh)) << 32;
+            const uint64_t got = cnt < 64u ? lo & ((uint64_t(1) << cnt) - 1) : lo;
+            if (n_bins < 64u) { bits0 |= got << n_bins; bits1 |= n_bins ? got >> (64u - n_bins) : 0u; }
+            else bits1 |= got << (n_bins - 64u);
+        }
+        n_bins += cnt > 64u ? kSegBits + 1u : cnt;              // a chunk with more than 64 of them: the string is not kept
+        chain_step<2>(tn, bw_cur, pos, end, w0, st);
+        bw_cur += 32;
+        e0 = e1; e1 = e2; e2 = e3; e3 = e4;
+        w0 = w1; w1 = w2;
+    }
+    SegSummary o;
+    o.bits[0] = bits0; o.bits[1] = bits1; o.n_bins = n_bins; o.exit_state = uint8_t(st[0]); o.met = st[0] == st[1]; o.met_chunk = uint16_t(met_chunk < 0xffffu ? met_chunk : 0xffffu);
+    summ[(size_t(L.s) * nk + k) * kChainSegs + L.seg] = o;
+}
+
+// A context's chain through chunks [c_first, c_first + n_ch) of its slice from state `st`, chunk by chunk (k_k1p_ctxchain's loop); NOTE: the
+// state at the start of every chunk goes to `est`.  Returns the state after the last chunk.
+template <bool NOTE>
+__device__ __forceinline__ uint32_t chain_chunks(const uint8_t *tn, const uint32_t *lbits, const uint16_t *lend, uint8_t *est, uint32_t nk, uint32_t row4,
+                                                 uint32_t k, uint32_t c_first, uint32_t n_ch, uint32_t st0) {
+    const uint16_t *le = lend + size_t(c_first) * nk + k;
+    const uint32_t *bw_ahead = lbits + size_t(c_first) * 32, *bw_cur = bw_ahead;
+    uint8_t *eo = est + size_t(c_first) * row4 + k;
+    auto ends = [&]() { const uint32_t e1 = le[0], em = le[-1]; le += nk; return make_uint2(k ? em : 0u, e1); };
+    auto window = [&](const uint32_t *bw, uint32_t pos) { const uint32_t wi = (pos >> 5) & 31u; return make_uint4(bw[wi], bw[wi + 1], bw[wi + 2], bw[wi + 3]); };
+    uint2 e0 = ends(), e1 = ends(), e2 = ends(), e3 = ends();
+    uint4 w0 = window(bw_ahead, e0.x), w1 = window(bw_ahead + 32, e1.x);
+    bw_ahead += 64;
+    uint32_t st[1] = {st0};
+    for (uint32_t c = 0; c < n_ch; c++) {
+        const uint2 e4 = ends();
+        const uint4 w2 = window(bw_ahead, e2.x);
+        bw_ahead += 32;
+        if (NOTE) { *eo = uint8_t(st[0]); eo += row4; }
+        if (st[0] < 126u) chain_step<1>(tn, bw_cur, e0.x, e0.y, w0, st);      // pStateIdx 63 never moves
+        bw_cur += 32;
+        e0 = e1; e1 = e2; e2 = e3; e3 = e4;
+        w0 = w1; w1 = w2;
+    }
+    return st[0];
+}
+
+__global__ __launch_bounds__(64 * kSegWaves) void k_k1p_chain_fix(Plan p, uint32_t n_slices, uint32_t groups, uint32_t chain_lanes, const int32_t *status,
+                                                       const uint8_t *tng, const uint32_t *lbits, const uint16_t *lend, const uint8_t *init_states,
+                                                       uint8_t *est, const SegSummary *summ, uint8_t *final_states, uint32_t force_walk_every) {
+    __shared__ uint8_t tn[kTnBytes];
+    for (uint32_t i = threadIdx.x; i < kTnBytes / 16; i += 64 * kSegWaves) reinterpret_cast<uint4 *>(tn)[i] = reinterpret_cast<const uint4 *>(tng)[i];
+    __syncthreads();
+    ChainLane L;
+    if (!chain_lane(p, n_slices, groups, chain_lanes, status, &L)) return;
+    const uint32_t nk = p.n_states, row4 = ((nk + 3) >> 2) << 2, k = L.k;
+    const SegSummary *mine = summ + (size_t(L.s) * nk + k) * kChainSegs;
+    const uint32_t init = init_states[size_t(L.s) * p.ns_full + L.col] & 127u;
+    const uint32_t c_slice = p.chunk_base[L.s], seg_len = (L.nc + kChainSegs - 1) / kChainSegs;
+    // test hook (always 0 in the product): for every n-th pair the summaries count for nothing -- every earlier segment is walked again
+    const bool distrust = force_walk_every && (L.s * nk + k) % force_walk_every == 0;
+    // The true entry state: back to the nearest segment whose walks met (or the slice's start), then forward through the ones between --
+    // their bins as a bit string where they fit, chunk by chunk where not.  A context parked at pStateIdx 63 stays there.
+    uint32_t from = L.seg, entry = init;
+    if (init < 126u) {
+        while (from > 0 && (distrust || !mine[from - 1].met)) from--;
+        if (from > 0) entry = mine[from - 1].exit_state;
+        for (uint32_t g = from; g < L.seg; g++) {
+            const SegSummary sg = mine[g];
+            if (sg.n_bins <= kSegBits && !distrust) {
+                uint64_t b = sg.bits[0], b_hi = sg.bits[1];
+                for (uint32_t left = sg.n_bins; left;) {
+                    const uint32_t n = left < 8u ? left : 8u;
+                    entry = tn[(128u << n) - 128u + (entry << n) + (uint32_t(b) & ((1u << n) - 1u))];
+                    b = (b >> 8) | (b_hi << 56); b_hi >>= 8; left -= n;
+                }
+            } else {
+                const uint32_t g_begin = g * seg_len < L.nc ? g * seg_len : L.nc, g_end = g_begin + seg_len < L.nc ? g_begin + seg_len : L.nc;
+                entry = chain_chunks<false>(tn, lbits, lend, est, nk, row4, k, c_slice + g_begin, g_end - g_begin, entry);
+            }
+        }
+    }
+    const SegSummary me = mine[L.seg];
+    const uint32_t n_ch = L.c_end - L.c_begin;
+    const bool met = me.met && init < 126u && !distrust;
+    const uint32_t stop = met && me.met_chunk < n_ch ? me.met_chunk : n_ch;          // chunks [0, stop): before the meeting point
+    const uint32_t exit_state = chain_chunks<true>(tn, lbits, lend, est, nk, row4, k, c_slice + L.c_begin, stop, entry);
+    // the slice's last segment that has chunks leaves the final state (an empty slice: its initial one)
+    if (final_states && (L.c_end == L.nc) && (L.c_begin < L.nc || L.seg == 0))
+        final_states[size_t(L.s) * p.ns_full + L.col] = uint8_t(stop < n_ch ? me.exit_state : exit_state);
+}
+
 __device__ __forceinline__ CodeEntry device_code_entry(uint32_t c);
 // per code: { low byte of rLPS << shift per range quarter, the shift per quarter } (see step_pair)
 __device__ __forceinline__ uint2 device_codes2(uint32_t c);
@@ -1074,18 +1283,18 @@ inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 // caller's context count; the kernels index it by the dense count, which is known after the census
 // (the one host round trip of the path: four bytes, to size the later launches).
 struct ResolveLayout {
-    uint64_t lbits, lend, est, stretch, meta, total;
+    uint64_t lbits, lend, est, stretch, meta, summ, total;
 };
 static inline ResolveLayout resolve_layout(size_t n_slices, uint32_t ns, const avr_chunk_plan *pl) {
     ResolveLayout L;
     uint64_t at = 0;
     auto take = [&](uint64_t bytes) { const uint64_t o = at; at += up256(bytes); return o; };
-    (void)n_slices;
     L.lbits = take(uint64_t(pl->total_chunks + 64) * 128);       // + 64 chunks: the chains read a few chunks ahead, unconditionally
     L.lend = take(uint64_t(pl->total_chunks + 64) * ns * 2 + 256) + 128;     // a pad in front: k_k1p_ctxchain reads lend[-1]
     L.est = take(uint64_t(pl->total_chunks) * ((ns + 3) / 4) * 4 + 16);
     L.stretch = take(uint64_t(pl->total_chunks) * sizeof(Stretch));
     L.meta = take(256 + 2048 + 2048 + kTnBytes);                 // used[32] + n_dense, table[1024], index[1024], tn
+    L.summ = take(uint64_t(n_slices) * ns * kChainSegs * sizeof(SegSummary));       // the segmented chains' summaries
     L.total = at;
     return L;
 }
@@ -1179,8 +1388,20 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
         chain_lanes = chain_lanes < kChainLanes ? kChainLanes : chain_lanes > 64 ? 64 : chain_lanes;
         if (const uint32_t v = test_hooks().chain_lanes) chain_lanes = v <= 64 ? v : 64;     // tuning switch (test build)
         const uint32_t groups = (n_states + chain_lanes - 1) / chain_lanes;
-        hipLaunchKernelGGL(k_k1p_ctxchain, dim3((n_slices * groups + kChainWaves - 1) / kChainWaves), dim3(64 * kChainWaves), 0, s, p,
-                           n_slices, groups, chain_lanes, status, tn, lbits, lend, init_states, est, final_states);
+        const dim3 whole((n_slices * groups + kChainWaves - 1) / kChainWaves), block(64 * kChainWaves);
+        // Long slices: the chains in kChainSegs segments (walks from both extreme states, see k_k1p_chain_seg), then whatever pair
+        // they could not settle start to end; short ones (a segment would be a chunk or two): start to end at once.
+        if (uint64_t(pl->total_chunks) >= uint64_t(n_slices) * 4 * kChainSegs && !test_hooks().chain_whole) {
+            SegSummary *summ = reinterpret_cast<SegSummary *>(w + L.summ);
+            const uint32_t seg_lanes = 64;                       // eight times the waves of the start-to-end walk: full ones
+            const uint32_t seg_groups = (n_states + seg_lanes - 1) / seg_lanes;
+            const dim3 seg_grid((n_slices * seg_groups * kChainSegs + kSegWaves - 1) / kSegWaves), seg_block(64 * kSegWaves);
+            hipLaunchKernelGGL(k_k1p_chain_seg, seg_grid, seg_block, 0, s, p, n_slices, seg_groups, seg_lanes, status, tn, lbits, lend, est, summ);
+            hipLaunchKernelGGL(k_k1p_chain_fix, seg_grid, seg_block, 0, s, p, n_slices, seg_groups, seg_lanes, status, tn, lbits, lend, init_states, est, summ,
+                               final_states, test_hooks().chain_force_redo);
+        } else {
+            hipLaunchKernelGGL(k_k1p_ctxchain, whole, block, 0, s, p, n_slices, groups, chain_lanes, status, tn, lbits, lend, init_states, est, final_states);
+        }
     }
     // the waves of a workgroup share the two tables (12 KiB, static); each has its own state rows: as many waves as fit (1 .. 4)
     const uint32_t per_wave = ((n_states + 8) / 4) * 256;

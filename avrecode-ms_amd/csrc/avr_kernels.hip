@@ -156,19 +156,99 @@ struct CabacLaneN {
     }
 };
 
+// The same bin with the emitter BASELINE.json's north star names -- "wavefront ballots used for output-bit packing": a digit is not
+// shifted into a register word but dropped into the lane's column of a staging area in LDS (16 slots of 64 lanes; slot-major, so
+// the data-dependent slot index never makes a bank conflict), and after every eight bins ONE ballot tells whether any lane has a
+// 16-byte row of eight digits ready; those lanes gather their row and store it whole.  Measured against the 8-byte register word
+// of CabacEncoder on config 5: kept as a test-build variant (hook k1_emit_lds), not shipped.
+struct alignas(8) Row16 { uint32_t x, y, z, w; };
+struct CabacLaneS {
+    CabacEncoder e;                                              // low / range; its byte writer takes over in finish()
+    uint32_t *stage;                                             // this lane's column: slot j at stage[64 j]
+    uint32_t cnt, flushed;                                       // digits produced / stored (flushed: a multiple of 8)
+
+    __device__ __forceinline__ void init(uint8_t *out, uint32_t capacity, uint32_t *column) {
+        e.init(0x7F800000u, out, capacity);
+        stage = column; cnt = flushed = 0;
+    }
+    __device__ void carry() {                                    // arithmetic_code.h:154-157: into the staged digits, then the stored bytes
+        for (uint32_t i = cnt; i > flushed;) {
+            i--;
+            const uint32_t d = (stage[64 * (i & 15u)] + 1u) & 0xffffu;
+            stage[64 * (i & 15u)] = d;
+            if (d) return;
+        }
+        uint32_t p = flushed * 2;
+        if (p > e.w.cap) return;
+        while (p > 0) {
+            p--;
+            const uint32_t b = uint32_t(e.w.base[p]) + 1u;
+            e.w.base[p] = uint8_t(b);
+            if (b <= 0xffu) break;
+        }
+    }
+    __device__ __forceinline__ void bin(uint32_t rec, uint32_t off, const uint2 *tab, uint8_t *st_lane) {
+        uint8_t *sp = st_lane + off;
+        uint32_t s = *sp;
+        asm volatile("" : "+v"(s));
+        uint2 ent = tab[s];
+        asm volatile("" : "+v"(ent.x), "+v"(ent.y));
+        const int norm = 23 - __builtin_clz(e.range);
+        const uint32_t q = (e.range >> (norm + 6)) & 3;
+        const uint32_t r_tab = ((ent.x >> (q * 8)) & 0xffu) << norm;
+        const uint32_t r1 = r_tab | ((e.range >> 1) & uint32_t(int32_t(ent.y) >> 31));
+        const uint32_t sym = (rec ^ s) & 1 & ~(ent.y >> 30);
+        const uint32_t r0 = e.range - r1;
+        e.low += sym ? r0 : 0u;
+        e.range = sym ? r1 : r0;
+        *sp = uint8_t(ent.y >> (8 * sym));
+        if (e.range < 0x200u) {                                  // arithmetic_code.h:115-122, the digit into the staging column
+            if (__builtin_expect(e.low >= CabacEncoder::kOne, 0)) { carry(); e.low -= CabacEncoder::kOne; }
+            stage[64 * (cnt & 15u)] = e.low >> 15;
+            cnt++;
+            e.low = (e.low & 0x7fffu) << 16;
+            e.range <<= 16;
+        }
+    }
+    __device__ __forceinline__ void rows() {                     // after every eight bins: at most 15 digits are staged at any time
+        const bool ready = cnt - flushed >= 8u;
+        if (__ballot(ready)) {
+            if (ready) {
+                uint32_t d[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) d[j] = stage[64 * ((flushed + j) & 15u)];
+                Row16 v;                                         // digits most significant byte first (arithmetic_code.h:184-190)
+                v.x = __builtin_bswap32(d[0] << 16 | d[1]); v.y = __builtin_bswap32(d[2] << 16 | d[3]);
+                v.z = __builtin_bswap32(d[4] << 16 | d[5]); v.w = __builtin_bswap32(d[6] << 16 | d[7]);
+                if (flushed * 2 + 16 <= e.w.cap) *reinterpret_cast<Row16 *>(e.w.base + flushed * 2) = v;
+                flushed += 8;
+            }
+        }
+    }
+    __device__ void finish() {                                   // what is still staged goes through the byte writer, then finish() as it stands
+        e.w.n = flushed * 2;
+        e.w.acc = 0;
+        for (uint32_t i = flushed; i < cnt; i++) e.w.put16_even(stage[64 * (i & 15u)]);
+        e.finish();
+    }
+};
+
 constexpr uint32_t kCensusStride = 16;                           // the one-lane-per-slice kernel renumbers from a 1-in-16 sample
 constexpr uint32_t kK1Waves = 4;                                 // waves per workgroup (fewer when the state rows are large): they share the two tables
 
 // table / index: the dense renumbering of the batch's contexts (k_k1p_densemap), or null: contexts as the caller
 // numbers them.  n_rows: contexts the kernel keeps states for (dense count, or n_states); init_states / final_states
 // rows are n_states wide, in the caller's numbering.
-template <bool TILED, bool NORM>
+// FORM: 0 = the coder as cabac_code.h writes it (CabacLane: shipped), 1 = normalised form (CabacLaneN), 2 = digits staged in LDS
+// (CabacLaneS); 1 and 2 are measured variants of the test build.
+template <bool TILED, int FORM>
 __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
     uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const uint16_t *table, const uint16_t *index, uint32_t n_rows,
     uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
     uint8_t *final_states, int32_t want_status) {
-    extern __shared__ uint32_t lds[];                            // per wave: state dwords [(n_rows + 4 + 3) / 4][64]
+    extern __shared__ uint32_t lds[];                            // per wave: state dwords [(n_rows + 4 + 3) / 4][64]; FORM 2: then 16 x 64 staging slots per wave
+    constexpr bool NORM = FORM == 1;
     __shared__ uint2 tab[136];                                   // 128 states + pseudo-states 128..135
     __shared__ uint32_t sel_off[2048];                           // selector -> byte offset of its state in the lane's column (up to 256 rows of 256 bytes, + 3)
 
@@ -225,10 +305,11 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     }
     __syncthreads();
 
-    typename std::conditional<NORM, CabacLaneN, CabacLane>::type L;
+    typename std::conditional<NORM, CabacLaneN, typename std::conditional<FORM == 2, CabacLaneS, CabacLane>::type>::type L;
     const uint64_t o0 = in_range ? out_off[slice] : 0;
     const uint32_t cap = in_range ? uint32_t(out_off[slice + 1] - o0) : 0;
     if constexpr (NORM) L.init(out + o0, cap);
+    else if constexpr (FORM == 2) L.init(out + o0, cap, lds + (blockDim.x >> 6) * rows4 * 64 + wv * 1024 + lane);
     else L.e.init(0x7F800000u, out + o0, cap);                   // cabac_code.h:30
 
     const ChunkSource<TILED> src(recs, off, in_range ? g : 0, slice);
@@ -252,6 +333,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
             const uint32_t rec = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
             L.bin(rec, offs[k], tab, st_lane);
             if constexpr (NORM) { if ((k & 3) == 3) L.digits(); }
+            if constexpr (FORM == 2) { if (k == 7) L.rows(); }
             const uint32_t t0 = rec == kTerm1 ? c * 8 + k : 0xffffffffu;
             term_at = term_at < t0 ? term_at : t0;
         }
@@ -262,7 +344,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
         if (active) {
             const bool missed = st_lane[(((n_rows + 3) >> 2) << 8) + ((n_rows + 3) & 3)] == 135u;
             if (term_at != 0xffffffffu && term_at + 1 < nb) st = AVR_SLICE_BAD_RECORD;   // a bin after finish()
-            else if constexpr (NORM) L.finish();
+            else if constexpr (FORM != 0) L.finish();
             else L.e.finish();                                   // cabac_code.h:63-65 / ~encoder(), arithmetic_code.h:100
             L.e.w.flush();
             if (st == AVR_SLICE_OK && L.e.w.n > cap) st = AVR_SLICE_OVERFLOW;
@@ -675,16 +757,16 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
             return err;                                          // contexts without bins keep their state
     }
     auto launch = [&](uint32_t rows, const uint16_t *tb, const uint16_t *ix, int32_t want) -> hipError_t {
-        const uint32_t per_wave = ((rows + 4 + 3) / 4) * 256;
+        const uint32_t per_wave = ((rows + 4 + 3) / 4) * 256 + (test_hooks().k1_emit_lds ? 4096u : 0u);     // (+ the staging slots of FORM 2)
         const uint32_t waves = per_wave * kK1Waves <= 60 * 1024 ? kK1Waves : per_wave * 2 <= 60 * 1024 ? 2 : 1;
         const uint32_t lds = waves * per_wave;
         const dim3 grid((n_slices + 64 * waves - 1) / (64 * waves)), block(64 * waves);
         // test hook k1_form_norm: the coder in normalised form with the digits taken every fourth bin, in step across the wave
         // (CabacLaneN).  Same bytes; measured on config 5 at the same 2.63 ms per step as the reference's form (what its
         // emit branch costs, the 64-bit low of the other form costs again), so the form that reads like cabac_code.h stays.
-        const bool norm = test_hooks().k1_form_norm != 0;
-        auto kern = tiled ? (norm ? k_cabac_encode<true, true> : k_cabac_encode<true, false>)
-                          : (norm ? k_cabac_encode<false, true> : k_cabac_encode<false, false>);
+        const int form = test_hooks().k1_form_norm ? 1 : test_hooks().k1_emit_lds ? 2 : 0;
+        auto kern = tiled ? (form == 1 ? k_cabac_encode<true, 1> : form == 2 ? k_cabac_encode<true, 2> : k_cabac_encode<true, 0>)
+                          : (form == 1 ? k_cabac_encode<false, 1> : form == 2 ? k_cabac_encode<false, 2> : k_cabac_encode<false, 0>);
         if (lds > 48 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
             if (e != hipSuccess) return e;

@@ -21,6 +21,8 @@
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
+#include <atomic>
+#include <thread>
 #include <map>
 #include <string>
 #include <vector>
@@ -916,6 +918,8 @@ class h264_stream_decoder : public host::stream_decoder {
     // Both directions of a file must agree on it (the container does not say which model wrote it).
     bool residual_hooks = false;
 
+    void expect_payload_questions() override { answers_ahead_ = true; }
+
     void decode_video(host::hooks *h, int (*read_packet)(void *, uint8_t *, int), void *opaque) override {
         std::vector<uint8_t> data, chunk(1 << 16);
         for (;;) {
@@ -925,38 +929,62 @@ class h264_stream_decoder : public host::stream_decoder {
         }
         std::vector<nal_ref> nals;
         if (!mp4_nals(data, &nals)) nals = annexb_nals(data);
+        // Pass 1, in stream order: parameter sets and slice headers (a header is read against the parameter sets in force where
+        // it stands).  Cheap: a few dozen bits per NAL unit.
+        std::vector<slice_job> jobs;
         for (const nal_ref &n : nals) {
             if (n.size < 2) continue;
             const uint8_t header = data[n.offset];
             const int type = header & 31, ref_idc = (header >> 5) & 3;
             if (type != 1 && type != 5 && type != 6 && type != 7 && type != 8) continue;
-            const std::vector<uint8_t> rbsp = unescape(&data[n.offset + 1], n.size - 1);
+            std::vector<uint8_t> rbsp = unescape(&data[n.offset + 1], n.size - 1);
             if (type == 6) { note_encoder(rbsp); continue; }
             if (type == 7 || type == 8) {
                 try { if (type == 7) parse_sps(rbsp, sps_); else parse_pps(rbsp, pps_); }
                 catch (const bad_stream &e) { stats.failed++; stats.last_reason = e.what(); }      // its slices will not find it
-            } else slice(h, rbsp, type, ref_idc);
+                continue;
+            }
+            slice_job j;
+            try {                                        // a header this build does not take: the slice is not offered to the hooks
+                j.sh = parse_slice_header(rbsp, type, ref_idc, sps_, pps_);
+                if (j.sh.data_offset >= rbsp.size()) throw bad_stream("slice without data");
+                j.sh.x264_old_444_cbf = j.sh.chroma_array_type == 3 && x264_build_ >= 0 && x264_build_ < 151;
+                j.header_ok = true;
+            } catch (const unsupported &e) { j.unsupported_header = true; j.reason = e.what(); }
+            catch (const bad_stream &e) { j.reason = std::string("header: ") + e.what(); }
+            j.rbsp = std::move(rbsp);
+            jobs.push_back(std::move(j));
         }
+        // Pass 2, when the compressor has said it will ask (expect_payload_questions): does each payload parse to its end?  One parse of
+        // the payload per slice with the build's own CABAC engine, slices independent of each other -- on all the host's cores.
+        if (answers_ahead_) {
+            host::phase_timer timer("parse: payload dry-runs");
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                std::vector<mb_info> scratch;            // one per thread, kept from slice to slice (a fresh half megabyte per slice is an mmap and its page faults each time)
+                for (size_t i; (i = next.fetch_add(1)) < jobs.size();)
+                    if (jobs[i].header_ok) jobs[i].decodes = dry_run(jobs[i], residual_hooks, &jobs[i].reason, &scratch) ? 1 : 0;
+            };
+            const char *forced = getenv("AVR_PARSE_THREADS");              // (the CLI's environment, like AVR_DEVICE: default = the host's cores, at most 16)
+            const unsigned hw = forced ? unsigned(atoi(forced)) : std::thread::hardware_concurrency();
+            const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 4, 16), jobs.size()));
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < n_threads; t++) pool.emplace_back(work);
+            work();
+            for (std::thread &t : pool) t.join();
+        }
+        // Pass 3, in stream order: the hooks.
+        host::phase_timer timer("parse: hooks in stream order");
+        for (slice_job &j : jobs) slice(h, j);
     }
 
     // compressor asks before it commits to the slice just offered: does the payload parse to its end?  (On the way back
     // the payload is a surrogate and nobody asks: the block kind says whether the slice was coded.)
     bool payload_decodes() override {
         if (!offered_) return false;
-        try {
-            engine_bins bins(offered_payload_, offered_size_);
-            uint8_t states[1024];
-            std::vector<mb_info> scratch(mbs_.size());
-            model_hooks dry;                             // no hooks fire; with the residual hooks on, the counts must fit their fields
-            dry.refuse_full_blocks = residual_hooks;
-            slice_parser<engine_bins> p(bins, offered_header_, states, scratch, 0, dry);
-            p.run();
-            return ends_cleanly(bins.d.bit_position(), offered_payload_, offered_size_);
-        } catch (const std::exception &e) {
-            stats.last_reason = e.what();
-            stats.literal_reasons[e.what()]++;
-            return false;
-        }
+        if (offered_->decodes < 0) offered_->decodes = dry_run(*offered_, residual_hooks, &offered_->reason, &dry_scratch_) ? 1 : 0;   // not worked out ahead
+        if (!offered_->decodes) { stats.last_reason = offered_->reason; stats.literal_reasons[offered_->reason]++; }
+        return offered_->decodes != 0;
     }
 
   private:
@@ -972,15 +1000,48 @@ class h264_stream_decoder : public host::stream_decoder {
         return ((p[stop >> 3] >> (7 - (stop & 7))) & 1) && (stop >> 3) == size - 1;
     }
 
-    void slice(host::hooks *h, const std::vector<uint8_t> &rbsp, int type, int ref_idc) {
-        stats.slices++;
+    struct slice_job {
+        std::vector<uint8_t> rbsp;                       // the unescaped NAL unit behind its header byte
         slice_header sh;
-        try {                                            // a header this build does not take: the slice is not offered to the hooks
-            sh = parse_slice_header(rbsp, type, ref_idc, sps_, pps_);
-            if (sh.data_offset >= rbsp.size()) throw bad_stream("slice without data");
-            sh.x264_old_444_cbf = sh.chroma_array_type == 3 && x264_build_ >= 0 && x264_build_ < 151;
-        } catch (const unsupported &e) { stats.unsupported++; stats.last_reason = e.what(); stats.literal_reasons[e.what()]++; return; }
-        catch (const bad_stream &e) { stats.failed++; stats.last_reason = e.what(); stats.literal_reasons[std::string("header: ") + e.what()]++; return; }
+        bool header_ok = false, unsupported_header = false;
+        int decodes = -1;                                // payload_decodes(): -1 not worked out yet, 0 / 1
+        std::string reason;                              // why not
+    };
+
+    // One parse of a slice's payload with the build's own CABAC engine, no hooks: true iff it ends on end_of_slice_flag in the
+    // payload's last byte.  Touches nothing of the decoder: slices can be dry-run side by side.
+    static bool dry_run(const slice_job &j, bool residual_hooks, std::string *why, std::vector<mb_info> *scratch_mbs) {
+        try {
+            const uint8_t *payload = j.rbsp.data() + j.sh.data_offset;
+            const size_t size = j.rbsp.size() - j.sh.data_offset;
+            engine_bins bins(payload, size);
+            uint8_t states[1024];
+            std::vector<mb_info> &scratch = *scratch_mbs;                 // (every entry the parser reads it has written in this slice: `slice` numbers tell)
+            const size_t n_mbs = size_t(j.sh.width_mbs) * j.sh.height_mbs;
+            if (scratch.size() != n_mbs) scratch.assign(n_mbs, mb_info());
+            else for (mb_info &m : scratch) m.slice = -1;
+            model_hooks dry;                             // no hooks fire; with the residual hooks on, the counts must fit their fields
+            dry.refuse_full_blocks = residual_hooks;
+            slice_parser<engine_bins> p(bins, j.sh, states, scratch, 0, dry);
+            p.run();
+            if (ends_cleanly(bins.d.bit_position(), payload, size)) return true;
+            *why = "the payload does not end on end_of_slice_flag in its last byte";
+            return false;
+        } catch (const std::exception &e) {
+            *why = e.what();
+            return false;
+        }
+    }
+
+    void slice(host::hooks *h, slice_job &j) {
+        stats.slices++;
+        if (!j.header_ok) {
+            if (j.unsupported_header) stats.unsupported++; else stats.failed++;
+            stats.last_reason = j.reason.rfind("header: ", 0) == 0 ? j.reason.substr(8) : j.reason;
+            stats.literal_reasons[j.reason]++;
+            return;
+        }
+        slice_header &sh = j.sh;
         // What frame_spec is told (recode.cpp:173): a number that is the same for the slices of a picture and differs from one
         // picture to the next.  frame_num itself repeats across a non-reference picture and the one after it, and h264_model
         // clears its per-picture store only when the number changes (update_frame_spec, recode.cpp:831-850): with the residual
@@ -989,11 +1050,11 @@ class h264_stream_decoder : public host::stream_decoder {
         sh.frame_num = pictures_;
         const size_t n_mbs = size_t(sh.width_mbs) * sh.height_mbs;
         if (mbs_.size() != n_mbs) mbs_.assign(n_mbs, mb_info());
-        const uint8_t *payload = rbsp.data() + sh.data_offset;
-        const size_t size = rbsp.size() - sh.data_offset;
-        offered_ = true; offered_payload_ = payload; offered_size_ = size; offered_header_ = sh;
+        const uint8_t *payload = j.rbsp.data() + sh.data_offset;
+        const size_t size = j.rbsp.size() - sh.data_offset;
+        offered_ = &j;
         void *dec = h->cabac.init_decoder(h->opaque, &cabac_context_identity_, payload, int(size));
-        offered_ = false;
+        offered_ = nullptr;
         if (!dec) return;                                // not hooked: nothing of this slice is needed later (no reconstruction)
         stats.hooked++;
         hook_bins bins{h, dec};
@@ -1022,10 +1083,9 @@ class h264_stream_decoder : public host::stream_decoder {
     uint8_t cabac_state_[1024];                          // the addresses get() hands to the hooks, as libavcodec's sl->cabac_state
     int cabac_context_identity_ = 0;                     // stands for the one CABACContext of a single-threaded decode (recode.cpp:153)
     int slice_counter_ = 0, pictures_ = 0;
-    bool offered_ = false;
-    const uint8_t *offered_payload_ = nullptr;
-    size_t offered_size_ = 0;
-    slice_header offered_header_;
+    slice_job *offered_ = nullptr;                       // the slice init_decoder is being called for
+    std::vector<mb_info> dry_scratch_;
+    bool answers_ahead_ = false;
 };
 
 }  // namespace h264

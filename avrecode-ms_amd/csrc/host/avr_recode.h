@@ -10,6 +10,9 @@
 // is not available offline; tests drive the same table from recorded slices (slice_feeder).
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 
 #include "avr_host.h"
@@ -51,6 +54,21 @@ struct stream_decoder {
     // trying.  "No" makes the compressor treat the slice like one whose payload it cannot find (skip_coded block,
     // the bytes stay literal): the container stays lossless whatever the parser can or cannot do.
     virtual bool payload_decodes() { return true; }
+    // Told by the compressor before decode_video: payload_decodes() will be asked about every slice.  A decoder whose answer
+    // costs a parse of the payload can then work the answers out ahead, for all slices at once (on several threads: slices
+    // parse independently of each other; only the hooks have to be called in stream order).
+    virtual void expect_payload_questions() {}
+};
+
+// AVR_TIMING=1: the phases of a run on stderr (the reference prints nothing of the kind; off by default)
+struct phase_timer {
+    const char *what;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit phase_timer(const char *w) : what(w) {}
+    ~phase_timer() {
+        static const bool on = getenv("AVR_TIMING") != nullptr;
+        if (on) fprintf(stderr, "[timing] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
 };
 
 inline void gpu_check(int rc) { if (rc < 0) throw std::runtime_error(std::string("avr: ") + avr_last_error()); }
@@ -128,10 +146,14 @@ class compressor {                                       // recode.cpp:1109-1316
 
     std::string run(stream_decoder *d) {                 // :1122-1132
         decoder_ = d;
+        d->expect_payload_questions();
         hooks h = hook_adapter<compressor>::make(this);
-        d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<compressor *>(o)->read_packet(buf, size); }, this);
-        cabac_contexts.clear();
-        code_pending();
+        {
+            phase_timer t("compress: parse + record");
+            d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<compressor *>(o)->read_packet(buf, size); }, this);
+            cabac_contexts.clear();
+        }
+        { phase_timer t("compress: GPU batch (K2)"); code_pending(); }
         Block final_literal;
         final_literal.has_literal = true;
         final_literal.literal = original_.substr(prev_coded_block_end_);
@@ -277,9 +299,12 @@ class decompressor {                                     // recode.cpp:1319-1598
         blocks_.clear();
         blocks_.resize(in_.block.size());
         hooks h = hook_adapter<decompressor>::make(this);
-        d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<decompressor *>(o)->read_packet(buf, size); }, this);
-        cabac_contexts.clear();
-        code_pending();
+        {
+            phase_timer t("decompress: K3 + parse");
+            d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<decompressor *>(o)->read_packet(buf, size); }, this);
+            cabac_contexts.clear();
+        }
+        { phase_timer t("decompress: GPU batch (K1)"); code_pending(); }
         std::string out;
         for (auto &block : blocks_) {
             if (!block.done) throw std::runtime_error("Not all blocks were decoded.");

@@ -164,6 +164,7 @@ void perf_test_driver(const std::string &directory_path) {
 int probe(const std::string &input_filename) {
     const std::string bytes = slurp(input_filename);
     h264::h264_stream_decoder dec;
+    dec.expect_payload_questions();                      // every slice is asked about: the answers are worked out ahead, on all cores
     struct counts { h264::h264_stream_decoder *d; size_t ok = 0, bad = 0; std::string why; } c{&dec};
     host::hooks h{};
     h.opaque = &c;

@@ -251,6 +251,9 @@ def main():
                          "workload's slice count is split over the ranks (contiguous ranges of near-equal bin totals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive block (host records in, host bytes out)")
+    ap.add_argument("--test-hook", action="append", default=[], metavar="NAME=VALUE",
+                    help="MEASUREMENT ONLY: run on the -DAVR_TEST_HOOKS build of the library with this hook set (csrc/avr_internal.h); "
+                         "the line says so in config.test_hooks.  The product library has no such switches")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL; gloo lets several ranks rehearse on one GPU)")
     args = ap.parse_args()
@@ -260,6 +263,10 @@ def main():
     import avrecode_ms_amd as avr
     from avrecode_ms_amd.sharding import balanced_ranges, reduce_timing, shard_first_slice
 
+    hooks_cm = None
+    if args.test_hook:
+        hooks_cm = avr.test_hooks(**{h.split("=")[0]: int(h.split("=")[1]) for h in args.test_hook})
+        hooks_cm.__enter__()                                 # for the rest of the process
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -363,7 +370,7 @@ def main():
                        "slices_per_gpu": n_slices, "batch_slices": batch_slices if args.scaling == "strong" else n_slices * world,
                        "bins_per_gpu": w.total_bins, "h264_bytes_per_gpu": out_bytes,
                        "h264_bytes_all_gpus": total_bytes // max(args.steps, 1),
-                       "n_states": w.n_states, "n_states_declared": declared_states,
+                       "n_states": w.n_states, "n_states_declared": declared_states, "test_hooks": args.test_hook or None,
                        "layout": "slice-major" if path == "chunked" else "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,

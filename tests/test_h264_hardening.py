@@ -100,7 +100,7 @@ def recode_asan(tmp_path_factory):
     if not cxx:
         pytest.skip("no g++")
     out = str(tmp_path_factory.mktemp("asan") / "recode_asan")
-    cmd = [cxx, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-I" + CSRC,
+    cmd = [cxx, "-O1", "-g", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-I" + CSRC,
            "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", out, os.path.join(CSRC, "host", "recode_main.cpp"),
            "-L" + PKG, "-lavrecode_hip", "-Wl,-rpath," + PKG]
     subprocess.run(cmd, check=True)

@@ -21,7 +21,7 @@ P = oracle_lib.ptr
 def host(avr):
     deps = [SRC, avr.LIB_PATH] + [os.path.join(CSRC, "host", f) for f in ("avr_host.h", "avr_recode.h", "avr_model.h", "avr_h264.h", "avr_h264_tables.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-I/opt/rocm/include",
+        subprocess.run(["g++", "-O2", "-pthread", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-I/opt/rocm/include",
                         "-D__HIP_PLATFORM_AMD__", "-o", SO, SRC, "-L" + os.path.dirname(avr.LIB_PATH), "-lavrecode_hip",
                         "-Wl,-rpath,$ORIGIN/../avrecode-ms_amd"], check=True)
     lib = ctypes.CDLL(SO)
