@@ -39,6 +39,7 @@ struct TestHooks {
     uint32_t k1_form_norm;           // one-lane-per-slice K1 in normalised form (CabacLaneN)
     uint32_t k1_emit_lds;            // one-lane-per-slice K1 with its digits staged in LDS and stored in 16-byte rows (CabacLaneS)
     uint32_t k1_path, no_dense, no_hint;   // the environment switches above, settable per test (non-zero wins over env())
+    uint32_t chain_segments;         // K1p: the context chains in segments whatever the batch's size
     uint32_t chain_whole;            // K1p: every context chain start to end (k_k1p_ctxchain alone), no segments
     uint32_t chain_force_redo;       // K1p: the segmented chains hand every n-th (slice, context) pair to the whole-slice walk
     uint32_t k2p_seg_len;            // chunks per segment of K2p's overlapped passes (0 = by batch shape): short slices through many segments

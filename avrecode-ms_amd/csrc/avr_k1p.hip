@@ -1391,7 +1391,12 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
         const dim3 whole((n_slices * groups + kChainWaves - 1) / kChainWaves), block(64 * kChainWaves);
         // Long slices: the chains in kChainSegs segments (walks from both extreme states, see k_k1p_chain_seg), then whatever pair
         // they could not settle start to end; short ones (a segment would be a chunk or two): start to end at once.
-        if (uint64_t(pl->total_chunks) >= uint64_t(n_slices) * 4 * kChainSegs && !test_hooks().chain_whole) {
+        // (what the segments buy is latency: eight times the lanes for an eighth of the dependent length.  Once a batch has lanes
+        // enough to keep the LDS busy with table look-ups -- config 4: 16 384 slices x 86 contexts -- they only add look-ups: measured
+        // 17.5 against 15.5 ms per step there, 0.277 against 0.289 ms for the chains of config 2's 512 slices, and the smaller the
+        // batch the larger the gain: the chains do not get shorter with fewer slices, everything else does.)
+        const bool few_lanes = uint64_t(n_slices) * n_states <= 49152;
+        if (uint64_t(pl->total_chunks) >= uint64_t(n_slices) * 4 * kChainSegs && !test_hooks().chain_whole && (few_lanes || test_hooks().chain_segments)) {
             SegSummary *summ = reinterpret_cast<SegSummary *>(w + L.summ);
             const uint32_t seg_lanes = 64;                       // eight times the waves of the start-to-end walk: full ones
             const uint32_t seg_groups = (n_states + seg_lanes - 1) / seg_lanes;

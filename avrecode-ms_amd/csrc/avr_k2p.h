@@ -91,9 +91,10 @@ AVR_K2P_HD bool range_step(uint64_t &range, uint32_t &bytes, uint32_t rec, Div &
 //   nb = 0 for a 1, 1 for a 0:
 //      qh = trunc(fma(H, inv, h))                 H / total                      (exact: H < 2^44)
 //      rh = fma(-qh, total, H)                    its remainder, < total
-//      a  = fma(rh, 2^32, L)                      |a| < 2^48: exact
-//      ql = floor(fma(a, inv, h))                 a / total, rounded down; exact for |a| < 2^51: (a + 1/2) / total is at least
-//                                                 1 / (2 total) away from an integer, the two roundings move it by |a / total| 2^-52
+//      a  = rh * 2^32 + L                         (|a| < 2^48; not formed: see the next line)
+//      ql = floor(fma(rh, 2^32 inv, fma(L, inv, h)))   a / total, rounded down; exact for |a| < 2^51: (a + 1/2) / total is at least
+//                                                 1 / (2 total) away from an integer, the three roundings move it by 1.5 |a / total| 2^-52.
+//                                                 The inner fma needs L alone, which is there when the bin begins: off the chain
 //   => range / total = qh * 2^32 + ql (recode.cpp:826), and the new range nb * range + (range / total) * ps
 //      (arithmetic_code.h:107-114) limb by limb:   H1 = fma(qh, ps, nb * H),  L1 = fma(ql, ps, nb * L)   (|L1| < 2^48)
 //      v  = fma(H1, 2^32, L1)                     the new range as ONE double: exact when it is below 2^53, and rounding is
@@ -102,11 +103,11 @@ AVR_K2P_HD bool range_step(uint64_t &range, uint32_t &bytes, uint32_t rec, Div &
 //      cL = (L1 + 1.5 * 2^84) - 1.5 * 2^84        L1 rounded to a multiple of 2^32 (the adder's own rounding)
 //      Hn = fma(cL, 2^-32, H1),  Ln = L1 - cL     the same value with |Ln| <= 2^31
 //      H = Hn * s,  L = Ln * s                    s = 1, 2^8 or 2^16: |L| <= 2^47
-// The comparison and the carry run side by side: the chain is t1, qh, rh, a, t2, ql, L1, v | t, cmp | cL, select, Hn, H.
+// The comparison and the carry run side by side: the chain is t1, qh, rh, t2, ql, L1, v | t, cmp | cL, select, select | Hn, H: 11 deep.
 // A new range below 2^39 (three or more bytes at once -- only a record with pos or neg 0 does that -- or zero: a bin of
 // probability zero) is outside what the two thresholds cover: vmin_hi notes it and the slice takes the integer form above.
 struct RangeFP { double H, L; };
-struct BinFP { double inv, h, d, ps, nb; };
+struct BinFP { double inv, h, d, ps, nb, inv32; };        // inv32 = 2^32 * inv (exact: a power of two)
 constexpr double kTwo32 = 4294967296.0, kInvTwo32 = 1.0 / 4294967296.0;
 constexpr double kSplit32 = 1.5 * 4294967296.0 * 4294967296.0 * 1048576.0;    // 1.5 * 2^84: ulp 2^32
 constexpr double kTwo51 = 2251799813685248.0, kTwo47 = 140737488355328.0, kTwo39 = 549755813888.0;
@@ -117,7 +118,7 @@ AVR_K2P_HD uint64_t fp_to_u64(const RangeFP &r) { return (uint64_t(r.H) << 32) +
 AVR_K2P_HD BinFP fp_operands(uint32_t rec) {
     const uint32_t pos = (rec >> 1) & 0x7fu, total = pos + ((rec >> 8) & 0x7fu), b = total ? rec & 1u : 0u;
     const double inv = total ? 1.0 / double(total) : 0.0;
-    return BinFP{inv, 0.5 * inv, double(total), b ? double(pos) : -double(pos), b ? 0.0 : 1.0};
+    return BinFP{inv, 0.5 * inv, double(total), b ? double(pos) : -double(pos), b ? 0.0 : 1.0, kTwo32 * inv};
 }
 // The constants of a step, as VALUES: the kernel keeps them in scalar registers (a 32-bit literal forces the compiler into
 // the two-operand form of the multiply-add, which overwrites an input that is still needed: a register copy per use).
@@ -132,8 +133,9 @@ AVR_K2P_HD uint32_t range_step_fp(RangeFP &r, uint32_t &vmin_hi, const BinFP &o,
     const double qh = __builtin_trunc(__builtin_fma(r.H, o.inv, o.h));
     const double rh = __builtin_fma(-qh, o.d, r.H);
     const double H1 = __builtin_fma(qh, o.ps, r.H * o.nb);
-    const double a = __builtin_fma(rh, K.two32, r.L);
-    const double ql = __builtin_floor(__builtin_fma(a, o.inv, o.h));
+    // (rh * 2^32 + L) / total as rh * (2^32 / total) + (L / total + h): the second term does not wait for the first division, which
+    // takes one multiply-add off the chain.  Three roundings of relative size 2^-53 instead of two: still exact for |a| < 2^51.
+    const double ql = __builtin_floor(__builtin_fma(rh, o.inv32, __builtin_fma(r.L, o.inv, o.h)));
     const double L1 = __builtin_fma(ql, o.ps, r.L * o.nb);
     const double v = __builtin_fma(H1, K.two32, L1);
     const double t = L1 + K.split32;

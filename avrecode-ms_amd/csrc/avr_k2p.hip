@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void k_k2p_ranges(K2Plan p, uint32_t n_slices, 
 // 1 / (2 total), total }, by (pos, bin): { +-pos, bin ? 0 : 1 } -- fetched for eight records before the first of them is
 // walked.  A slice with a new range below 2^39 anywhere (a record with pos or neg 0, or a bin of probability zero) is handed
 // to k_k2p_ranges (status AVR_SLICE_RETRY_SERIAL), which covers everything.  Also validates: bit 15 of a record must be clear.
-struct TotEntry { double inv, h, d, pad; };
+struct TotEntry { double inv, h, d, inv32; };             // 1 / total, 1 / (2 total), total, 2^32 / total
 struct PosEntry { double ps, nb; };
 //
 // The walk is launched in SEGMENTS of chunks [seg_begin, seg_end) of every slice (a lane picks up its range and byte count from
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slice
     __shared__ PosEntry pos_tab[256];
     for (uint32_t d = threadIdx.x; d < 256; d += 64) {
         const double inv = d ? 1.0 / double(d) : 0.0;
-        tot_tab[d] = TotEntry{inv, 0.5 * inv, double(d), 0.0};
+        tot_tab[d] = TotEntry{inv, 0.5 * inv, double(d), 4294967296.0 * inv};
         const uint32_t pos = d >> 1, b = d & 1u;
         pos_tab[d] = PosEntry{b ? double(pos) : -double(pos), b ? 0.0 : 1.0};
     }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slice
             const uint32_t pos16 = sh ? (wk >> 12) & 0xff0u : (wk << 4) & 0xff0u;
             const TotEntry te = *reinterpret_cast<const TotEntry *>(reinterpret_cast<const uint8_t *>(tot_tab) + total32);
             const PosEntry pe = *reinterpret_cast<const PosEntry *>(reinterpret_cast<const uint8_t *>(pos_tab) + pos16);
-            o[k] = BinFP{te.inv, te.h, te.d, pe.ps, pe.nb};
+            o[k] = BinFP{te.inv, te.h, te.d, pe.ps, pe.nb, te.inv32};
         }
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) pos8 += range_step_fp(rg, vmin_hi, o[k], K);

@@ -489,7 +489,9 @@ def test_context_chains_in_segments(avr, oracle, hooks, mode):
     if mode == "whole":
         hooks(chain_whole=1)
     elif mode == "redo3":
-        hooks(chain_force_redo=3)
+        hooks(chain_force_redo=3, chain_segments=1)
+    else:
+        hooks(chain_segments=1)
     rng = np.random.default_rng(606)
     slices = []
     for n in (65536, 131072 + 777, 40000, 8 * 1024, 5 * 1024 + 3, 300000):
