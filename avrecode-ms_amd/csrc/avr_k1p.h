@@ -333,8 +333,9 @@ AVR_HD uint32_t ref_digits(uint32_t t) { return t <= 21 ? 0 : (t - 21 + 15) / 16
 // ------------------------------------------------------------------ phase C (one lane per active stretch)
 
 // Digit sums: 32-bit per 16-bit digit of the slice's code string.  `Adder` supplies
-//   void store(uint32_t digit_index, uint32_t v)   exclusive position, plain store
+//   void store(uint32_t digit_index, uint32_t v)   exclusive position, plain store; called with consecutive indices
 //   void add(uint32_t digit_index, uint32_t v)     shared position, atomic add
+//   void flush()                                   no store() follows: whatever the adder holds back goes out
 // A stretch shares its first two digits with the windows of earlier stretches and its final
 // window (two digits) with later ones; everything between is its own (argument in DESIGN.md).
 //
@@ -407,6 +408,7 @@ AVR_HD void c_stretch_in(const Src &src, const Stretch &st, const Entry &en, uin
         for (; base + 16 <= to; base += 16) group16(src.load16(base));
         if (base < to) for_codes_in(src, base, to, [&](uint32_t, uint32_t c) { bin(c); digits(); return false; });
     }
+    S.flush();
     // what is left is the coder's window: the top of digit g0 + j (with any carry) and 15 - e bits of the next
     if (sp >= 0) {
         S.add(g0 + j, uint32_t(L2 >> (sp + 1)));

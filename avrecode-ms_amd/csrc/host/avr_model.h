@@ -198,7 +198,11 @@ class h264_model {
         return probability_for_model_key(range, get_model_key(context));
     }
 
-    // ---- frame store (recode.cpp:831-850)
+    // ---- frame store (recode.cpp:831-850).  This function and update_state_tracking below follow the reference branch for
+    // branch, on purpose: they ARE the model's state machine -- when a picture's store is cleared, which of significant_coeff_flag
+    // and last_significant_coeff_flag a bin is, when the last coefficient is implied -- and the recoded bytes depend on every
+    // branch of them, so there is one way to write them that decodes the reference's files.  What is this build's own is the data
+    // they run on: integer keys, a flat estimator array, a frame store of plain vectors, neighbour geometry as bit arithmetic.
     void update_frame_spec(int frame_num, int mb_width, int mb_height) {
         const uint32_t w = uint32_t(mb_width), h = uint32_t(mb_height);
         if (frames[cur_frame].width() == w && frames[cur_frame].height() == h && frames[cur_frame].is_same_frame(frame_num)) return;

@@ -19,6 +19,7 @@ struct HostAdder {
     std::vector<uint32_t> &S;
     void store(uint32_t i, uint32_t v) { S[i] = v; stores++; }
     void add(uint32_t i, uint32_t v) { S[i] += v; adds++; }
+    void flush() {}
     size_t stores = 0, adds = 0;
 };
 }  // namespace

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Turn one tools/gpu_final.sh run (gpurun_out/TAG/) into the committed summaries under profiles/:
-   python tools/collect_profiles.py TAG ROUND        e.g.  fin2 r01
+"""Turn one tools/gpu_final_r3.sh run (gpurun_out/TAG/, parts a, b, c) into the committed summaries under profiles/:
+   python tools/collect_profiles.py TAG ROUND        e.g.  fin3 r03
 kernel-trace stats and the PMC counter files are copied as they are (kernels of this library only for
 the counters); pmc_traffic.json is what bench.py's roofline.traffic reads."""
 import collections
@@ -30,7 +30,7 @@ def short(name):
 
 
 SQ_STEPS = 2         # ... and the SQ counter pass with --steps 1 --warmup 1
-PMC_STEPS = 4        # tools/gpu_final.sh runs the counter passes with --steps 3 --warmup 1: four identical steps
+PMC_STEPS = 4        # the counter passes run with --steps 3 --warmup 1: four identical steps
 
 
 def per_kernel(path, counter, steps_key="avr::"):
@@ -48,7 +48,10 @@ def per_kernel(path, counter, steps_key="avr::"):
 
 traffic = {}
 for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches of one step"),
-                      (5, "cabac_serial_w5_s1048576", "k_k1_census + k_k1p_densemap + k_cabac_encode<tiled>: all launches of one step")):
+                      (5, "cabac_serial_w5_s1048576", "k_k1_census + k_k1p_densemap + k_cabac_encode<tiled>: all launches of one step"),
+                      ("5lds", "cabac_serial_w5_s1048576_test_hook_k1_emit_lds", "the same with the LDS-row emitter (test build, hook k1_emit_lds): a measured variant")):
+    if not glob.glob(os.path.join(src, f"w{w}_stats")):
+        continue
     shutil.copy(one(f"w{w}_stats/**/*kernel_stats.csv"), os.path.join(dst, f"{rnd}_w{w}_kernel_stats.csv"))
     for what in ("fetch", "write"):
         rows = [r for r in csv.DictReader(open(one(f"w{w}_{what}/**/*counter_collection.csv"))) if "avr::" in r["Kernel_Name"]]
@@ -81,13 +84,22 @@ for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches o
             wr.writerow([k] + ["%.6g" % (agg[(k, c)] / SQ_STEPS) for c in names])   # per step: all launches of the run / its steps
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
-for b in ("w2", "w3", "w4", "w5", "w5_k2", "w2_resolved", "w2_k2", "w4_k2"):
-    p = os.path.join(src, f"bench_{b}.json")
-    if os.path.exists(p):
-        shutil.copy(p, os.path.join(dst, f"{rnd}_bench_{b}.json"))
+for d in ("w2k2", "w4k2"):                               # kernel stats of the compress direction
+    hits = glob.glob(os.path.join(src, f"{d}_stats/**/*kernel_stats.csv"), recursive=True)
+    if hits:
+        shutil.copy(hits[0], os.path.join(dst, f"{rnd}_{d}_kernel_stats.csv"))
+benches = sorted(os.path.basename(p)[len("bench_"):-len(".json")] for p in glob.glob(os.path.join(src, "bench_*.json")))
+for b in benches:
+    shutil.copy(os.path.join(src, f"bench_{b}.json"), os.path.join(dst, f"{rnd}_bench_{b}.json"))
+for extra in ("cli_timing.txt",):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{rnd}_{extra}"))
+reh = os.path.join(ROOT, "gpurun_out", "rehearsal_2ranks_w4.json")
+if os.path.exists(reh):
+    shutil.copy(reh, os.path.join(dst, f"{rnd}_rehearsal_2ranks_w4.json"))
 for key, t in traffic.items():
     print(key, "HBM bytes per step: %.3f GB" % (t["hbm_bytes_per_launch"] / 1e9))
-for b in ("w2", "w3", "w4", "w5", "w5_k2", "w2_resolved", "w2_k2", "w4_k2"):
+for b in benches:
     p = os.path.join(dst, f"{rnd}_bench_{b}.json")
     if os.path.exists(p):
         j = json.loads(open(p).read().strip().splitlines()[-1])

@@ -81,6 +81,30 @@ CHAIN_KERNEL(k_fma_f64_x4, double x = (double)seed; double y = x + 1; double z =
 CHAIN_KERNEL(k_mad_u64_u32_x2, uint64_t x = seed; uint64_t y = seed + 1; uint32_t a = 3,
              asm volatile("v_mad_u64_u32 %0, vcc, %2, %2, %0\n v_mad_u64_u32 %1, vcc, %2, %2, %1" : "+v"(x), "+v"(y) : "v"(a) : "vcc");, x + y)
 
+// The K2 range recurrence itself (range_step_fp of csrc/avr_k2p.h) with operands that are already in registers: what one bin
+// costs when nothing but the chain is there (no record unpacking, no table look-ups, no loads).
+#include "../../avrecode-ms_amd/csrc/avr_k2p.h"
+__global__ void k_range_step_fp(uint64_t *out, uint64_t seed) {
+    using namespace avr::k2p;
+    RangeFP r = fp_from_u64(kOne - seed);
+    FpConsts K = fp_consts();
+    asm volatile("" : "+s"(K.two32), "+s"(K.inv_two32), "+s"(K.split32), "+s"(K.two51), "+s"(K.two47));
+    BinFP o[4] = {fp_operands(1 | (3 << 1) | (5 << 8)), fp_operands(0 | (9 << 1) | (2 << 8)), fp_operands(1 | (40 << 1) | (41 << 8)), fp_operands(0 | (1 << 1) | (90 << 8))};
+    for (int k = 0; k < 4; k++) asm volatile("" : "+v"(o[k].inv), "+v"(o[k].h), "+v"(o[k].d), "+v"(o[k].ps), "+v"(o[k].nb), "+v"(o[k].inv32));
+    uint32_t vmin = 0xffffffffu, bits = 0;
+    uint64_t t0 = 0, t1 = 0;
+    for (int w = 0; w < 2; w++) {
+        t0 = __builtin_readcyclecounter();
+        for (int i = 0; i < ITER * 4; i++) {
+            bits += range_step_fp(r, vmin, o[0], K); bits += range_step_fp(r, vmin, o[1], K);
+            bits += range_step_fp(r, vmin, o[2], K); bits += range_step_fp(r, vmin, o[3], K);
+        }
+        t1 = __builtin_readcyclecounter();
+    }
+    if (threadIdx.x == 0) out[0] = t1 - t0;
+    out[1 + threadIdx.x] = fp_to_u64(r) + bits + vmin;
+}
+
 struct Test { const char *name; void (*fn)(uint64_t *, uint64_t); int per_body; };
 #define T(n, k) {#n, n, k}
 
@@ -94,6 +118,12 @@ int main() {
         T(k_s_add_u32, 1), T(k_s_mul_i32, 1), T(k_s_mul_hi_u32, 1), T(k_s_lshl_b64, 1), T(k_s_flbit_b64, 2), T(k_s_cselect, 2), T(k_s_addc_pair, 2),
         T(k_fma_f64_x2, 2), T(k_fma_f64_x4, 4), T(k_mad_u64_u32_x2, 2),
     };
+    for (int lanes : {64, 1}) {                              // cycles per BIN of the K2 range recurrence, operands in registers
+        hipLaunchKernelGGL(k_range_step_fp, dim3(1), dim3(lanes), 0, 0, d, 12345ull);
+        uint64_t h = 0;
+        hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+        printf("%-20s lanes %2d: %7.2f cycles per bin (%llu cycles / %d bins)\n", "range_step_fp", lanes, double(h) / (ITER * 16), (unsigned long long)h, ITER * 16);
+    }
     for (const Test &t : tests) {
         for (int lanes : {64, 32, 1}) {
             hipLaunchKernelGGL(t.fn, dim3(1), dim3(lanes), 0, 0, d, 12345ull);
