@@ -18,14 +18,15 @@ if [ "$PART" = a ]; then
   timeout -k 10 600 python3 -m pytest $R/tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
   tail -1 $O/tests.log
   bench w2; bench w3 --workload 3; bench w4 --workload 4; bench w5 --workload 5
+  bench w2_resolved --records resolved --no-cpu-baseline --no-e2e
+  bench w2_s128 --slices 128 --no-cpu-baseline --no-e2e
+  bench w2_s128_whole_chains --slices 128 --no-cpu-baseline --no-e2e --test-hook chain_whole=1
+  $R/tools/ubench/chain_latency > $O/chain_latency.txt 2>&1; tail -2 $O/chain_latency.txt
 elif [ "$PART" = b ]; then
   bench w2_k2 --workload 2 --kind range --steps 5 --warmup 1
   bench w4_k2 --workload 4 --kind range --steps 5 --warmup 1
   bench w5_k2 --workload 5 --kind range
   bench w3_k2 --workload 3 --kind range --steps 2 --warmup 1 --no-cpu-baseline --no-e2e
-  bench w2_resolved --records resolved --no-cpu-baseline --no-e2e
-  bench w2_s128 --slices 128 --no-cpu-baseline --no-e2e
-  bench w2_s128_whole_chains --slices 128 --no-cpu-baseline --no-e2e --test-hook chain_whole=1
   bench w5_lds_rows --workload 5 --no-cpu-baseline --no-e2e --test-hook k1_emit_lds=1
 else
   SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
