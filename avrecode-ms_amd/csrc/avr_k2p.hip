@@ -128,25 +128,34 @@ __global__ __launch_bounds__(64) void k_k2p_ranges(K2Plan p, uint32_t n_slices, 
 }
 
 // Pass 1, double-precision form (range_step_fp, avr_k2p.h): the same chunk notes from a chain of 12 dependent
-// instructions per bin instead of 24.  A record's operands come from two small LDS tables -- by total: { 1 / total,
-// 1 / (2 total), total }, by (pos, bin): { +-pos, bin ? 0 : 1 } -- fetched for eight records before the first of them is
-// walked.  A slice with a new range below 2^39 anywhere (a record with pos or neg 0, or a bin of probability zero) is handed
+// instructions per bin instead of 24.  A record's operands come from small LDS tables -- by total: { 1 / total,
+// 1 / (2 total) } and { total, 2^32 / total }, by (pos, bin): { +-pos, bin ? 0 : 1 }.  A slice with a new range below 2^39 anywhere (a record with pos or neg 0, or a bin of probability zero) is handed
 // to k_k2p_ranges (status AVR_SLICE_RETRY_SERIAL), which covers everything.  Also validates: bit 15 of a record must be clear.
-struct TotEntry { double inv, h, d, inv32; };             // 1 / total, 1 / (2 total), total, 2^32 / total
-struct PosEntry { double ps, nb; };
+struct TotA { double inv, h; };                           // by 2 total + bin: 1 / total, 1 / (2 total)
+struct TotB { double d, inv32; };                         // by 2 total + bin: total, 2^32 / total
+struct PosEntry { double ps, nb; };                       // by the record's low byte (2 pos + bin): +-pos, bin ? 0 : 1
+//
+// A lone wave issues one instruction every four to five cycles whatever it is, and the walk is bound by that count (about 30 a
+// bin), not by the chain alone (tools/ubench/chain_latency: 105 cycles a bin with the operands in registers): so the tables are
+// laid out for the fewest address instructions -- every entry 16 bytes and both tables by total indexed by 2 total + bin, which
+// is the record's low byte plus twice its high byte: (low byte << 4) addresses PosEntry, that plus (high byte << 5) the other
+// two -- and the operands of a group of eight records are fetched while the group BEFORE it is walked, so that no wait for LDS
+// ever stalls the chain.
 //
 // The walk is launched in SEGMENTS of chunks [seg_begin, seg_end) of every slice (a lane picks up its range and byte count from
 // the note of chunk seg_begin, which the segment before it left): pass 2 of a segment then runs on a second stream while pass 1
 // walks the next one -- pass 1 keeps a handful of the chip's 1 024 SIMDs busy, pass 2 takes the rest (launch_k2p).
 __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
                                                      uint64_t *fin_range, uint32_t *fin_pos, int32_t *status, uint32_t seg_begin, uint32_t seg_end) {
-    __shared__ TotEntry tot_tab[256];
+    __shared__ TotA tot_a[512];
+    __shared__ TotB tot_b[512];
     __shared__ PosEntry pos_tab[256];
-    for (uint32_t d = threadIdx.x; d < 256; d += 64) {
+    for (uint32_t i = threadIdx.x; i < 512; i += 64) {
+        const uint32_t d = i >> 1;
         const double inv = d ? 1.0 / double(d) : 0.0;
-        tot_tab[d] = TotEntry{inv, 0.5 * inv, double(d), 4294967296.0 * inv};
-        const uint32_t pos = d >> 1, b = d & 1u;
-        pos_tab[d] = PosEntry{b ? double(pos) : -double(pos), b ? 0.0 : 1.0};
+        tot_a[i] = TotA{inv, 0.5 * inv};
+        tot_b[i] = TotB{double(d), 4294967296.0 * inv};
+        if (i < 256) pos_tab[i] = PosEntry{(i & 1u) ? double(d) : -double(d), (i & 1u) ? 0.0 : 1.0};
     }
     __syncthreads();
     const uint32_t s = blockIdx.x * 64 + threadIdx.x;
@@ -162,23 +171,36 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slice
     asm volatile("" : "+s"(K.two32), "+s"(K.inv_two32), "+s"(K.split32), "+s"(K.two51), "+s"(K.two47));   // in scalar registers, see FpConsts
     uint32_t vmin_hi = 0xffffffffu;
     uint32_t pos8 = seg_begin ? ck_pos[c0 + seg_begin] * 8u : 0u, high = 0;          // pos8: BITS shifted out so far
-    auto group = [&](const U4 &v) {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        high |= (w[0] | w[1]) | (w[2] | w[3]);
-        BinFP o[8];
+    // a padding record (0) reads { -0, 1 }: a 0 of probability one.  Anything else with total 0, or pos 0 and bin 1, makes a
+    // range of zero, which vmin_hi notes.
+    uint32_t four = 4;
+    asm volatile("" : "+v"(four));
+    auto fetch = [&](uint32_t w0, uint32_t w1, BinFP o[4]) {     // half a group: the operands of four records
+        high |= w0 | w1;
+        uint32_t pos16[4], hi7[4], tot16[4];
+        // (low byte of the record) << 4 is one SDWA shift; + (high byte << 5): a bit-field extract and a shift-add
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(pos16[0]) : "v"(four), "v"(w0));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(pos16[1]) : "v"(four), "v"(w0));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(pos16[2]) : "v"(four), "v"(w1));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(pos16[3]) : "v"(four), "v"(w1));
+        hi7[0] = __builtin_amdgcn_ubfe(w0, 8, 7); hi7[1] = __builtin_amdgcn_ubfe(w0, 24, 7);
+        hi7[2] = __builtin_amdgcn_ubfe(w1, 8, 7); hi7[3] = __builtin_amdgcn_ubfe(w1, 24, 7);
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            // a padding record (0) reads { -0, 1 }: a 0 of probability one.  Anything else with total 0, or pos 0 and bin 1, makes a
-            // range of zero, which vmin_hi notes.
-            const uint32_t wk = w[k >> 1], sh = 16 * (k & 1);
-            const uint32_t total32 = (((wk >> (sh + 1)) & 0x7fu) + ((wk >> (sh + 8)) & 0x7fu)) << 5;
-            const uint32_t pos16 = sh ? (wk >> 12) & 0xff0u : (wk << 4) & 0xff0u;
-            const TotEntry te = *reinterpret_cast<const TotEntry *>(reinterpret_cast<const uint8_t *>(tot_tab) + total32);
-            const PosEntry pe = *reinterpret_cast<const PosEntry *>(reinterpret_cast<const uint8_t *>(pos_tab) + pos16);
-            o[k] = BinFP{te.inv, te.h, te.d, pe.ps, pe.nb, te.inv32};
+        for (uint32_t k = 0; k < 4; k++) asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(tot16[k]) : "v"(hi7[k]), "v"(pos16[k]));
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const TotA ta = *reinterpret_cast<const TotA *>(reinterpret_cast<const uint8_t *>(tot_a) + tot16[k]);
+            const TotB tb = *reinterpret_cast<const TotB *>(reinterpret_cast<const uint8_t *>(tot_b) + tot16[k]);
+            const PosEntry pe = *reinterpret_cast<const PosEntry *>(reinterpret_cast<const uint8_t *>(pos_tab) + pos16[k]);
+            o[k] = BinFP{ta.inv, ta.h, tb.d, pe.ps, pe.nb, tb.inv32};
         }
+        __builtin_amdgcn_sched_barrier(0);                       // the reads stay here, ahead of the walk below them (a lone wave is
+                                                                 // bound by its instruction count, not by where the fills sit)
+    };
+    auto walk = [&](const BinFP o[4]) {
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) pos8 += range_step_fp(rg, vmin_hi, o[k], K);
+        for (uint32_t k = 0; k < 4; k++) pos8 += range_step_fp(rg, vmin_hi, o[k], K);
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto note = [&](uint32_t g) { ck_range[c0 + (g >> 7)] = fp_to_u64(rg); ck_pos[c0 + (g >> 7)] = pos8 >> 3; };
     auto line = [&](uint32_t g, U4 v[4]) {
@@ -186,21 +208,31 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slice
         for (uint32_t k = 0; k < 4; k++) v[k] = r[g + k < last ? g + k : last];
     };
     U4 cur[4], nx1[4];
-    if (n_groups) { line(g_begin, cur); line(g_begin + 4, nx1); }
+    BinFP oa[4], ob[4];
+    if (n_groups) { line(g_begin, cur); line(g_begin + 4, nx1); fetch(cur[0].x, cur[0].y, oa); }
     uint32_t g = g_begin;
     for (; g + 4 <= g_end; g += 4) {                             // (g_end is a whole number of lines unless it is the slice's end)
         U4 nx2[4];
         line(g + 8, nx2);
         if ((g & (kChunk / 8 - 1)) == 0) note(g);
-        group(cur[0]); group(cur[1]); group(cur[2]); group(cur[3]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0), here where it costs nothing: all that is in flight is the
+                                                                 // trip before's last fetch, a walk old (else the compiler waits behind the next)
+        fetch(cur[0].z, cur[0].w, ob); walk(oa);
+        fetch(cur[1].x, cur[1].y, oa); walk(ob);
+        fetch(cur[1].z, cur[1].w, ob); walk(oa);
+        fetch(cur[2].x, cur[2].y, oa); walk(ob);
+        fetch(cur[2].z, cur[2].w, ob); walk(oa);
+        fetch(cur[3].x, cur[3].y, oa); walk(ob);
+        fetch(cur[3].z, cur[3].w, ob); walk(oa);
+        fetch(nx1[0].x, nx1[0].y, oa); walk(ob);                 // (behind the slice's end: a copy of its last group, never walked)
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) { cur[k] = nx1[k]; nx1[k] = nx2[k]; }
     }
     if (g < g_end) {                                             // the slice's last, partial line (chunks start on whole lines)
         if ((g & (kChunk / 8 - 1)) == 0) note(g);
-        group(cur[0]);
-        if (g + 1 < g_end) group(cur[1]);
-        if (g + 2 < g_end) group(cur[2]);
+        fetch(cur[0].z, cur[0].w, ob); walk(oa); walk(ob);
+        if (g + 1 < g_end) { fetch(cur[1].x, cur[1].y, oa); fetch(cur[1].z, cur[1].w, ob); walk(oa); walk(ob); }
+        if (g + 2 < g_end) { fetch(cur[2].x, cur[2].y, oa); fetch(cur[2].z, cur[2].w, ob); walk(oa); walk(ob); }
     }
     if (g_end < n_groups) note(g_end);                           // where the next segment picks up
     else {
