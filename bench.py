@@ -351,11 +351,14 @@ def main():
         achieved = algo / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per step by PMC: not measured by this run -- the figure of the committed rocprofv3 --pmc passes over this
         # very command (profiles/pmc_traffic.json, made by tools/collect_profiles.py), or null
-        traffic, traffic_source = None, None
+        # (`traffic`: FETCH_SIZE doubled throughout, the guide's gfx950 rule and an upper bound here; `traffic_calibrated`: with the
+        # factors measured on known byte counts in this library's access patterns, profiles/r03_hbm_counter_calibration.txt)
+        traffic, traffic_cal, traffic_source = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not args.test_hook:
             try:
-                traffic = json.load(open(tpath)).get(f"{args.kind}_{path}_w{args.workload}_s{n_slices}", {}).get("hbm_bytes_per_launch")
+                t = json.load(open(tpath)).get(f"{args.kind}_{path}_w{args.workload}_s{n_slices}", {})
+                traffic, traffic_cal = t.get("hbm_bytes_per_launch"), t.get("hbm_bytes_per_launch_calibrated")
                 traffic_source = "profiles/pmc_traffic.json" if traffic is not None else None
             except Exception:
                 traffic = None
@@ -373,7 +376,7 @@ def main():
                        "n_states": w.n_states, "n_states_declared": declared_states, "test_hooks": args.test_hook or None,
                        "layout": "slice-major" if path == "chunked" else "wave-interleaved tiles", "path": path, "records": args.records, "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_calibrated": traffic_cal, "traffic_source": traffic_source,
                          "kernel": (K1P_KERNELS if path == "chunked" else
                                     "k_k1_census (1-in-16 sample) + k_k1p_densemap + k_cabac_encode<tiled> + its hand-back launch (one step = all of them)")
                          if kind == avr.KIND_CABAC else

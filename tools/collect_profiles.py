@@ -46,6 +46,7 @@ def per_kernel(path, counter, steps_key="avr::"):
     return {k: sum(v) / PMC_STEPS for k, v in by.items()}
 
 
+LANE_CHUNK_READERS = ("k_k1p_local", "k_k1p_replay", "k_k1p_chain", "k_k1p_ctxchain", "k_k2p_code", "k_k2p_ranges", "k_cabac_encode", "k_range_encode")
 traffic = {}
 for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches of one step"),
                       (5, "cabac_serial_w5_s1048576", "k_k1_census + k_k1p_densemap + k_cabac_encode<tiled>: all launches of one step"),
@@ -62,13 +63,17 @@ for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches o
     fetch = per_kernel(one(f"w{w}_fetch/**/*counter_collection.csv"), "FETCH_SIZE")
     write = per_kernel(one(f"w{w}_write/**/*counter_collection.csv"), "WRITE_SIZE")
     fsum, wsum = sum(fetch.values()), sum(write.values())
+    # profiles/r03_hbm_counter_calibration.txt: a lane that walks a chunk of its own reads 1.2 .. 1.5 x what FETCH_SIZE says, not 2 x
+    fcal = sum(v * (1.5 if any(k.startswith(n) for n in LANE_CHUNK_READERS) else 2.0) for k, v in fetch.items())
     traffic[key] = {
         "kernel": label, "FETCH_SIZE_KB_raw_sum": fsum, "WRITE_SIZE_KB_raw_sum": wsum,
         "fetch_bytes_corrected_x2": fsum * 1024 * 2, "write_bytes": wsum * 1024,
         "hbm_bytes_per_launch": fsum * 1024 * 2 + wsum * 1024,
+        "fetch_bytes_calibrated": fcal * 1024, "hbm_bytes_per_launch_calibrated": fcal * 1024 + wsum * 1024,
         "per_kernel_FETCH_SIZE_KB": fetch, "per_kernel_WRITE_SIZE_KB": write,
-        "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE), all launches of the run / its 4 steps; FETCH_SIZE "
-                "doubled per the gfx950 wide-read rule (uncalibrated for byte gathers)"}
+        "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE), all launches of the run / its 4 steps; hbm_bytes_per_launch: "
+                "FETCH_SIZE doubled throughout (the guide's gfx950 wide-read rule, an upper bound here); ..._calibrated: x1.5 for "
+                "the kernels that read a chunk per lane, x2 for the rest (profiles/r03_hbm_counter_calibration.txt)"}
     # issue / wait counters of the same workload, one line per kernel
     sq = one(f"w{w}_sq/**/*counter_collection.csv")
     agg, cnt = collections.defaultdict(float), collections.Counter()
