@@ -98,15 +98,26 @@ AVR_HD CodeEntry code_entry(uint32_t c, const uint32_t *rows /* rows[p], p = pSt
 
 // One bin on the normalised range, branch-free: returns the renormalisation shift it causes
 // (= bits of output).  A bypass bin has row 0: rLPS = 0 leaves R alone, and meta adds its one shift.
+// Either side's renormalisation is "shift the new range up to nine bits" (the MPS side's range - rLPS lies in [128, 511]:
+// one shift iff below 256; the LPS side's is rLPS itself, cabac_code.h:40-41), so the side is chosen first and one count of
+// leading zeros serves both: four instructions where a shift per side and two selects are eight.
+AVR_HD int clz32_nz(uint32_t x) { return __builtin_clz(x); }   // x != 0
 AVR_HD uint32_t step_range(const CodeEntry &e, uint32_t *R) {
     const uint32_t rl = (e.row >> ((*R >> 3) & 24)) & 0xffu;   // quarter (R >> 6) & 3 selects the byte
     const uint32_t rm = *R - rl;                           // MPS side: range - rLPS
-    const uint32_t shm = ((rm >> 8) & 1u) ^ 1u;            // rm in [128, 511]: one shift iff below 256
-    const uint32_t shl = uint32_t(clz32(rl)) - 23;         // LPS side: range = rLPS (cabac_code.h:40-41)
-    const bool sym = e.meta & 1u;
-    const uint32_t sh = sym ? shl : shm;                   // selects, not a branch: both sides are two instructions
-    *R = (sym ? rl : rm) << sh;
+    const uint32_t x = (e.meta & 1u) ? rl : rm;            // never 0: a coded LPS has rLPS >= 2, rm >= 128
+    const uint32_t sh = uint32_t(clz32_nz(x)) - 23;
+    *R = x << sh;
     return sh + (e.meta >> 8);
+}
+
+// The same entry laid out for phase C's inner loop (16 bytes, one LDS read): the symbol in the sign bit of `flags` (a
+// compare against zero), bypass in its bit 0, and what a bin adds to low as two masks -- 2 (range - rLPS) & m_rm | range & m_r
+// (cabac_code.h:37-39 for a coded symbol 1, :52-54 for a bypass 1; both zero for a 0).
+struct alignas(16) CodeEntryC { uint32_t row, flags, m_rm, m_r; };
+AVR_HD CodeEntryC code_entry_c(const CodeEntry &e) {
+    const uint32_t sym = e.meta & 1u, adds = (e.meta >> 1) & 1u, byp = e.meta >> 8;
+    return CodeEntryC{e.row, sym << 31 | byp, (adds && !byp) ? ~0u : 0u, (adds && byp) ? ~0u : 0u};
 }
 
 // ------------------------------------------------------------------ phase B1
@@ -196,6 +207,10 @@ AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g,
 AVR_HD void code_entries4(const CodeEntry *codes, uint32_t d, CodeEntry e[4]) {
     e[0] = codes[d & 0xffu]; e[1] = codes[(d >> 8) & 0xffu]; e[2] = codes[(d >> 16) & 0xffu]; e[3] = codes[d >> 24];
     AVR_PIN2(e[0].row, e[0].meta); AVR_PIN2(e[1].row, e[1].meta); AVR_PIN2(e[2].row, e[2].meta); AVR_PIN2(e[3].row, e[3].meta);
+}
+AVR_HD void code_entries4(const CodeEntryC *codes, uint32_t d, CodeEntryC e[4]) {
+    e[0] = codes[d & 0xffu]; e[1] = codes[(d >> 8) & 0xffu]; e[2] = codes[(d >> 16) & 0xffu]; e[3] = codes[d >> 24];
+    AVR_PIN2(e[0].row, e[0].flags); AVR_PIN2(e[1].row, e[1].flags); AVR_PIN2(e[2].row, e[2].flags); AVR_PIN2(e[3].row, e[3].flags);
 }
 
 AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const CodeEntry *codes, uint32_t max_stretch,
@@ -351,7 +366,7 @@ AVR_HD uint32_t ref_digits(uint32_t t) { return t <= 21 ? 0 : (t - 21 + 15) / 16
 // already in it (it can reach 2^17); the sums are integers and phase D carries them on.
 template <class Src, class Adder>
 AVR_HD void c_stretch_in(const Src &src, const Stretch &st, const Entry &en, uint32_t chunk,
-                         const CodeEntry *codes, Adder &S) {
+                         const CodeEntryC *codes, Adder &S) {
     uint32_t R, from;
     if (chunk == 0) { R = 510; from = 0; }
     else { uint32_t sh; R = post_lps_range(codes[src.byte(st.first)].row, en.q, &sh); from = st.first + 1; }
@@ -359,16 +374,14 @@ AVR_HD void c_stretch_in(const Src &src, const Stretch &st, const Entry &en, uin
     uint64_t L2 = 0;
     int sp = int(phase) - 7;                               // e = 22 - phase at the start (cabac_code.h:30 shifted onto the digit grid)
     uint32_t j = 0;                                        // digits produced
-    auto bin_e = [&](const CodeEntry &e) {
+    auto bin_e = [&](const CodeEntryC &e) {
         const uint32_t rl = (e.row >> ((R >> 3) & 24)) & 0xffu;
         const uint32_t rm = R - rl;
-        const uint32_t shm = ((rm >> 8) & 1u) ^ 1u;
-        const uint32_t shl = uint32_t(clz32(rl)) - 23;
-        const bool sym = e.meta & 1u, byp = e.meta >> 8;
-        const uint32_t v = byp ? R : 2 * rm;               // what a 1 adds to low, in half units
-        const uint32_t sh0 = sym ? shl : shm, sh = sh0 + (e.meta >> 8);
-        L2 = (L2 + ((e.meta & 2u) ? v : 0u)) << sh;
-        R = (sym ? rl : rm) << sh0;
+        const uint32_t x = int32_t(e.flags) < 0 ? rl : rm; // the side coded (step_range)
+        const uint32_t sh0 = uint32_t(clz32_nz(x)) - 23, sh = sh0 + (e.flags & 1u);
+        const uint32_t v = ((2 * rm) & e.m_rm) | (R & e.m_r);  // what the bin adds to low, in half units
+        L2 = (L2 + v) << sh;
+        R = x << sh0;
         sp += int(sh);
     };
     auto bin = [&](uint32_t c) { bin_e(codes[c]); };
@@ -384,7 +397,7 @@ AVR_HD void c_stretch_in(const Src &src, const Stretch &st, const Entry &en, uin
     const uint32_t to = st.end;
     if (from < to) {
         auto four = [&](uint32_t d) {                      // 4 bins shift by at most 28: sp <= 14 + 28, L2 < 2^61
-            CodeEntry e[4];
+            CodeEntryC e[4];
             code_entries4(codes, d, e);
             bin_e(e[0]); bin_e(e[1]); bin_e(e[2]); bin_e(e[3]);
             digits();
@@ -420,7 +433,7 @@ AVR_HD void c_stretch_in(const Src &src, const Stretch &st, const Entry &en, uin
 
 template <class Adder>
 AVR_HD void c_stretch(const uint8_t *res, const Stretch &st, const Entry &en, uint32_t chunk,
-                      const CodeEntry *codes, Adder &S) {
+                      const CodeEntryC *codes, Adder &S) {
     c_stretch_in(LinearCodes{res}, st, en, chunk, codes, S);
 }
 

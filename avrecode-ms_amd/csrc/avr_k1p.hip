@@ -1113,8 +1113,8 @@ template <bool TILE_CODES>
 __global__ __launch_bounds__(256) void k_k1p_c(Plan p, uint32_t total_chunks, const uint8_t *res,
                                                const Stretch *st, const Entry *en, const SliceTotals *tot,
                                                uint32_t *S) {
-    __shared__ CodeEntry codes[256];
-    codes[threadIdx.x] = device_code_entry(threadIdx.x);
+    __shared__ CodeEntryC codes[256];
+    codes[threadIdx.x] = code_entry_c(device_code_entry(threadIdx.x));
     __syncthreads();
     const uint32_t gc = blockIdx.x * 256 + threadIdx.x;
     if (gc >= total_chunks) return;

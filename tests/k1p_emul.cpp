@@ -64,8 +64,10 @@ size_t k1p_emul_encode_resolved(const uint8_t *res, size_t n, uint8_t *out, size
     std::vector<uint32_t> S(nd + 4, 0);
     HostAdder add{S};
     uint32_t active = 0;
+    CodeEntryC codes_c[256];
+    for (uint32_t c = 0; c < 256; c++) codes_c[c] = code_entry_c(codes[c]);
     for (uint32_t c = 0; c < n_chunks; c++)
-        if (st[c].first != kNone) { c_stretch(res, st[c], en[c], c, codes, add); active++; }
+        if (st[c].first != kNone) { c_stretch(res, st[c], en[c], c, codes_c, add); active++; }
     const uint32_t len = d_slice(S.data(), tot, out, uint32_t(cap));
     if (info) {
         info[0] = active; info[1] = tot.t_total; info[2] = tot.r_final; info[3] = tot.bad;
