@@ -100,10 +100,27 @@ AVR_HD CodeEntry code_entry(uint32_t c, const uint32_t *rows /* rows[p], p = pSt
 // (= bits of output).  A bypass bin has row 0: rLPS = 0 leaves R alone, and meta adds its one shift.
 // Either side's renormalisation is "shift the new range up to nine bits" (the MPS side's range - rLPS lies in [128, 511]:
 // one shift iff below 256; the LPS side's is rLPS itself, cabac_code.h:40-41), so the side is chosen first and one count of
-// leading zeros serves both: four instructions where a shift per side and two selects are eight.
+// leading zeros serves both.
 AVR_HD int clz32_nz(uint32_t x) { return __builtin_clz(x); }   // x != 0
+// rangeTabLPS[p][(range >> 6) & 3] out of the state's row (one byte per quarter), range in [256, 511]
+AVR_HD uint32_t lps_range(uint32_t row, uint32_t R) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one byte permute: range >> 6 is 4 .. 7, which as a selector means bytes 0 .. 3 of the first operand; the selector's
+    // other three bytes are 0 = byte 0 of the second operand, the constant 0
+    return __builtin_amdgcn_perm(row, 0u, R >> 6);
+#else
+    return (row >> ((R >> 3) & 24)) & 0xffu;
+#endif
+}
+AVR_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
 AVR_HD uint32_t step_range(const CodeEntry &e, uint32_t *R) {
-    const uint32_t rl = (e.row >> ((*R >> 3) & 24)) & 0xffu;   // quarter (R >> 6) & 3 selects the byte
+    const uint32_t rl = lps_range(e.row, *R);
     const uint32_t rm = *R - rl;                           // MPS side: range - rLPS
     const uint32_t x = (e.meta & 1u) ? rl : rm;            // never 0: a coded LPS has rLPS >= 2, rm >= 128
     const uint32_t sh = uint32_t(clz32_nz(x)) - 23;
@@ -111,13 +128,25 @@ AVR_HD uint32_t step_range(const CodeEntry &e, uint32_t *R) {
     return sh + (e.meta >> 8);
 }
 
-// The same entry laid out for phase C's inner loop (16 bytes, one LDS read): the symbol in the sign bit of `flags` (a
-// compare against zero), bypass in its bit 0, and what a bin adds to low as two masks -- 2 (range - rLPS) & m_rm | range & m_r
-// (cabac_code.h:37-39 for a coded symbol 1, :52-54 for a bypass 1; both zero for a 0).
-struct alignas(16) CodeEntryC { uint32_t row, flags, m_rm, m_r; };
+// The same entry laid out for the inner loops (16 bytes, one LDS read), every field an operand as it stands:
+//   side   all ones for a coded symbol 1 (the LPS side), else 0: the new range is a bit-field insert of rLPS over range - rLPS
+//   k      what the bin adds to low, in half units, as a factor of range - rLPS: 2 for a coded symbol 1 (cabac_code.h:37-39),
+//          1 for a bypass 1 (:52-54: the range itself, rLPS being 0 there), 0 otherwise
+//   adj    bypass - 23: leading zeros of the new range + adj = the bits the bin shifts out
+struct alignas(16) CodeEntryC { uint32_t row, side, k, adj; };
 AVR_HD CodeEntryC code_entry_c(const CodeEntry &e) {
     const uint32_t sym = e.meta & 1u, adds = (e.meta >> 1) & 1u, byp = e.meta >> 8;
-    return CodeEntryC{e.row, sym << 31 | byp, (adds && !byp) ? ~0u : 0u, (adds && byp) ? ~0u : 0u};
+    return CodeEntryC{e.row, sym ? ~0u : 0u, adds ? (byp ? 1u : 2u) : 0u, byp - 23u};
+}
+// One bin: the new range, what it adds to low (*v), returns the shift (the range's own: *sh0)
+AVR_HD uint32_t step_range_c(const CodeEntryC &e, uint32_t *R, uint32_t *v) {
+    const uint32_t rl = lps_range(e.row, *R);
+    const uint32_t rm = *R - rl;
+    const uint32_t x = (rl & e.side) | (rm & ~e.side);
+    const uint32_t lz = uint32_t(clz32_nz(x));
+    *v = mul24(rm, e.k);
+    *R = x << (lz - 23);
+    return lz + e.adj;
 }
 
 // ------------------------------------------------------------------ phase B1
@@ -210,7 +239,7 @@ AVR_HD void code_entries4(const CodeEntry *codes, uint32_t d, CodeEntry e[4]) {
 }
 AVR_HD void code_entries4(const CodeEntryC *codes, uint32_t d, CodeEntryC e[4]) {
     e[0] = codes[d & 0xffu]; e[1] = codes[(d >> 8) & 0xffu]; e[2] = codes[(d >> 16) & 0xffu]; e[3] = codes[d >> 24];
-    AVR_PIN2(e[0].row, e[0].flags); AVR_PIN2(e[1].row, e[1].flags); AVR_PIN2(e[2].row, e[2].flags); AVR_PIN2(e[3].row, e[3].flags);
+    AVR_PIN2(e[0].row, e[0].side); AVR_PIN2(e[1].row, e[1].side); AVR_PIN2(e[2].row, e[2].side); AVR_PIN2(e[3].row, e[3].side);
 }
 
 AVR_HD void b1_stretch(const uint8_t *res, uint32_t n, uint32_t chunk, const CodeEntry *codes, uint32_t max_stretch,
@@ -375,13 +404,9 @@ AVR_HD void c_stretch_in(const Src &src, const Stretch &st, const Entry &en, uin
     int sp = int(phase) - 7;                               // e = 22 - phase at the start (cabac_code.h:30 shifted onto the digit grid)
     uint32_t j = 0;                                        // digits produced
     auto bin_e = [&](const CodeEntryC &e) {
-        const uint32_t rl = (e.row >> ((R >> 3) & 24)) & 0xffu;
-        const uint32_t rm = R - rl;
-        const uint32_t x = int32_t(e.flags) < 0 ? rl : rm; // the side coded (step_range)
-        const uint32_t sh0 = uint32_t(clz32_nz(x)) - 23, sh = sh0 + (e.flags & 1u);
-        const uint32_t v = ((2 * rm) & e.m_rm) | (R & e.m_r);  // what the bin adds to low, in half units
+        uint32_t v;
+        const uint32_t sh = step_range_c(e, &R, &v);
         L2 = (L2 + v) << sh;
-        R = x << sh0;
         sp += int(sh);
     };
     auto bin = [&](uint32_t c) { bin_e(codes[c]); };

@@ -700,7 +700,8 @@ __device__ __forceinline__ uint32_t step_pair(uint32_t &Rp, uint32_t row, uint32
 
 // Phase B1 as the kernels walk it (the logic of b1_stretch, avr_k1p.h, which stays the CPU's statement of it): a chunk's
 // stretch summary from its bins in order, eight at a time.  A bin comes as the table entry { x: LPS ranges of its state's
-// four range quarters, y: (code << 8) | (meta << 16) } (k_k1p_replay has it from its state look-up, k_k1p_b1 from the code).
+// four range quarters, y: (code << 8) | (meta << 16), z, w: CodeEntryC's side and adj } (k_k1p_replay has it from its state
+// look-up, k_k1p_b1 from the code).
 // mode: 0 = looking for the LPS that opens the stretch, 1 = four candidate ranges, 2 = they have met, 3 = closed.
 struct B1Walk {
     uint32_t i0, i1, limit, n, max_stretch;
@@ -722,7 +723,7 @@ struct B1Walk {
         Tp0 = Tp1 = 0;
     }
     __device__ __forceinline__ bool met() const { return Rp0 == Rp1 && (Rp0 >> 16) == (Rp0 & 0xffffu); }
-    __device__ __forceinline__ void one(uint32_t idx, const uint2 &e) {       // bin idx (< n), any mode
+    __device__ __forceinline__ void one(uint32_t idx, const uint4 &e) {       // bin idx (< n), any mode
         const CodeEntry ce{e.x, e.y >> 16};
         const bool boundary = ce.meta & 1u;                      // a coded LPS (code_is_boundary)
         if (mode == 0) {
@@ -746,15 +747,19 @@ struct B1Walk {
         } else if (mode == 2) {
             const bool closing = idx >= limit && boundary;
             if (closing) o.exit_q = uint8_t(((Rm >> 6) & 3) * 0x55u);
-            Tm += step_range(ce, &Rm);
+            Tm += step_merged(e);
             if (closing) { end = idx + 1; mode = 3; }
             else if (idx >= limit && idx - i0 > max_stretch) { o.too_long = 1; end = idx + 1; mode = 3; }
         }
     }
-    __device__ __forceinline__ void group(uint32_t base, const uint2 e[8]) {  // bins base .. base+7
+    __device__ __forceinline__ uint32_t step_merged(const uint4 &e) {         // step_range on the one range left
+        uint32_t v;
+        return step_range_c(CodeEntryC{e.x, e.z, 0u, e.w}, &Rm, &v);
+    }
+    __device__ __forceinline__ void group(uint32_t base, const uint4 e[8]) {  // bins base .. base+7
         if (mode == 2 && base + 8 <= i1) {                       // merged and inside the chunk: nothing can close the stretch
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) { const CodeEntry ce{e[j].x, e[j].y >> 16}; Tm += step_range(ce, &Rm); }
+            for (uint32_t j = 0; j < 8; j++) Tm += step_merged(e[j]);
         } else if (mode == 1 && base + 8 <= i1) {                // four candidates, inside the chunk: the same, and no branch per bin
 #pragma unroll
             for (uint32_t j = 0; j < 8; j++) {
@@ -773,7 +778,7 @@ struct B1Walk {
         }
     }
     __device__ __forceinline__ void chunk_done() { if (mode == 0) mode = 3; }  // no LPS in the chunk: no stretch opens here (first stays kNone)
-    __device__ __forceinline__ void tail(uint32_t base, const uint2 e[8]) {      // past the chunk, until the stretch closes
+    __device__ __forceinline__ void tail(uint32_t base, const uint4 e[8]) {      // past the chunk, until the stretch closes
         for (uint32_t j = 0; j < 8; j++) if (base + j < n && mode != 3) one(base + j, e[j]);
         flush_t();
     }
@@ -794,7 +799,7 @@ template <bool TILE_CODES>
 __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunks, const uint32_t *est, uint8_t *res,
                                                     const int32_t *status, Stretch *stretch, uint32_t max_stretch) {
     extern __shared__ uint32_t replay_lds[];                     // per wave: state dwords [(nk+8)/4][64]
-    __shared__ uint2 info[2 * kReplayStates];
+    __shared__ uint4 info[2 * kReplayStates];
     __shared__ uint2 codes2[256];
     __shared__ uint32_t sel_off[2048];
     const uint32_t lane = threadIdx.x & 63, nk = p.n_states;
@@ -819,7 +824,8 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
             code = st == kStBypass ? kCodeBypass | bin : st == kStTerminate ? code_terminate(bin) : kCodePad;
         }
         const CodeEntry ce = device_code_entry(code);
-        info[i] = make_uint2(ce.row, next | code << 8 | ce.meta << 16);
+        const CodeEntryC cc = code_entry_c(ce);
+        info[i] = make_uint4(ce.row, next | code << 8 | ce.meta << 16, cc.side, cc.adj);
     }
     __syncthreads();
     const uint32_t gc = blockIdx.x * blockDim.x + threadIdx.x;
@@ -850,7 +856,7 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
     B1Walk b1;
     b1.init(c, i0, i1, n, max_stretch, codes2);
     // 8 records (16 bytes) -> 8 codes; e[] = their table entries
-    auto eight = [&](const U4 &v, uint32_t &c0, uint32_t &c1, uint2 e[8]) {
+    auto eight = [&](const U4 &v, uint32_t &c0, uint32_t &c1, uint4 e[8]) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t off[8];
 #pragma unroll
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
                 n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
             }
             U4 a, b;
-            uint2 e[8];
+            uint4 e[8];
             eight(v0, a.x, a.y, e); b1.group(i, e);
             eight(v1, a.z, a.w, e); b1.group(i + 8, e);
             eight(v2, b.x, b.y, e); b1.group(i + 16, e);
@@ -896,7 +902,7 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
             const U4 nop{AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2};
             const U4 t0 = q[0], t1 = i + 8 < i1 ? q[1] : nop;
             U4 a;
-            uint2 e[8];
+            uint4 e[8];
             eight(t0, a.x, a.y, e); b1.group(i, e);
             eight(t1, a.z, a.w, e); b1.group(i + 8, e);
             put16(i, a);
@@ -905,7 +911,7 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
         // past the chunk: on through the next chunk's bins until the stretch closes (codes not written: not this lane's)
         for (i = i0 + kChunk; b1.mode != 3 && i < n; i += 8) {
             uint32_t c0, c1;
-            uint2 e[8];
+            uint4 e[8];
             eight(*reinterpret_cast<const U4 *>(r + i), c0, c1, e);
             b1.tail(i, e);
         }
@@ -936,11 +942,12 @@ __device__ __forceinline__ uint2 device_codes2(uint32_t c) {
 // `tile` != null: the chunk's codes are also written there wave-interleaved (TileCodes), for phase C to read.
 __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, const uint8_t *res,
                                                 const int32_t *status, Stretch *st, uint32_t max_stretch, uint8_t *tile) {
-    __shared__ uint2 cinfo[256];                                 // per code: { LPS ranges of its state, (code << 8) | (meta << 16) }
+    __shared__ uint4 cinfo[256];                                 // per code: { LPS ranges of its state, (code << 8) | (meta << 16), side, adj }
     __shared__ uint2 codes2[256];
     {
         const CodeEntry ce = device_code_entry(threadIdx.x);
-        cinfo[threadIdx.x] = make_uint2(ce.row, threadIdx.x << 8 | ce.meta << 16);
+        const CodeEntryC cc = code_entry_c(ce);
+        cinfo[threadIdx.x] = make_uint4(ce.row, threadIdx.x << 8 | ce.meta << 16, cc.side, cc.adj);
         codes2[threadIdx.x] = device_codes2(threadIdx.x);
     }
     __syncthreads();
@@ -953,14 +960,14 @@ __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, c
     const uint8_t *r = res + p.res_off[slice];
     B1Walk b1;
     b1.init(c, i0, i1, n, max_stretch, codes2);
-    auto eight = [&](uint32_t lo, uint32_t hi, uint2 e[8]) {     // eight codes, first in lo's low byte
+    auto eight = [&](uint32_t lo, uint32_t hi, uint4 e[8]) {     // eight codes, first in lo's low byte
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++) e[j] = cinfo[((j < 4 ? lo : hi) >> (8 * (j & 3))) & 0xffu];
     };
     uint8_t *to = tile ? tile + ((size_t(gc >> 6) * 64) * 64 + (gc & 63u)) * 16 : nullptr;
     auto sixteen = [&](uint32_t base, const U4 &v) {
         if (to) *reinterpret_cast<U4 *>(to + size_t((base - i0) >> 4) * 1024) = v;
-        uint2 e[8];
+        uint4 e[8];
         eight(v.x, v.y, e); b1.group(base, e);
         eight(v.z, v.w, e); b1.group(base + 8, e);
     };
@@ -979,7 +986,7 @@ __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, c
         b1.chunk_done();
         for (i = i0 + kChunk; b1.mode != 3 && i < n; i += 16) {  // past the chunk, until the stretch closes
             const U4 v = *reinterpret_cast<const U4 *>(r + i);
-            uint2 e[8];
+            uint4 e[8];
             eight(v.x, v.y, e); b1.tail(i, e);
             if (b1.mode != 3) { eight(v.z, v.w, e); b1.tail(i + 8, e); }
         }
