@@ -215,10 +215,13 @@ __global__ __launch_bounds__(256) void k_k1p_tn(uint8_t *tn) {
 //                           put_terminate(1) is anywhere but last (the terminate row holds a 1 that is not the
 //                           slice's last bin: a handful of bits to look at per chunk);
 //   AVR_SLICE_RETRY_CENSUS  (internal) if row nk + 2 is not empty, counting such slices in *n_retry.
-__global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks, int32_t *status, uint32_t *lbits,
+// SelT: uint16_t while the offsets fit (up to 500 contexts) -- with 86 contexts eight waves' rows and a table of 4 KiB are the
+// CU's 160 KiB to the byte -- uint32_t beyond.
+template <class SelT>
+__global__ __launch_bounds__(512) void k_k1p_local(Plan p, uint32_t total_chunks, int32_t *status, uint32_t *lbits,
                                                    uint16_t *lend, uint32_t *n_retry) {
     extern __shared__ uint32_t local_lds[];                      // per wave: bits[33][64], then cnt[(nk + 5) / 2][64] (two 16-bit counters each)
-    __shared__ uint32_t sel_tab[2048];
+    __shared__ SelT sel_tab[2048];
     const uint32_t nk = p.n_states, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t cnt_rows = (nk + 5) / 2;                      // contexts 0 .. nk-1 and the rows nk .. nk+3
     const uint32_t wave_dwords = (33 + cnt_rows) * 64;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void k_k1p_local(Plan p, uint32_t total_chunks
             const uint32_t d = p.table[sel];
             k = d < nk ? d : sel < p.ns_full ? nk + 2 : nk + 3;
         } else k = sel == AVR_SEL_TERMINATE ? nk : (sel == AVR_SEL_BYPASS || sel == (AVR_NOP_CABAC >> 1)) ? nk + 1 : nk + 3;
-        sel_tab[sel] = (k >> 1) * 256u | (k & 1u) * 16u;
+        sel_tab[sel] = SelT((k >> 1) * 256u | (k & 1u) * 16u);
     }
     for (uint32_t i = lane; i < wave_dwords; i += 64) bits[i] = 0;
     __syncthreads();
@@ -1388,14 +1391,33 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
     p.n_states = n_states;
     {
         // the waves of a workgroup share the renumbering table; each has its own counters and bit strings
+        // as many waves to a CU as its LDS takes (the kernel waits on LDS round trips: two waves a SIMD against one and a half is
+        // what there is to win), as workgroups of w waves: the w with the most waves resident, the smaller workgroup on a tie
         const uint32_t per_wave = (33 + (n_states + 5) / 2) * 64 * 4;
-        const uint32_t waves = per_wave * 4 <= 60 * 1024 ? 4 : per_wave * 2 <= 60 * 1024 ? 2 : 1;
-        const uint32_t lds = waves * per_wave;
+        const bool narrow = n_states <= 500;                     // (rows up to (n_states + 3) / 2 = 251: offsets below 2^16)
+        const uint32_t kLdsPerCu = 160 * 1024, kStatic = narrow ? 2048 * 2 : 2048 * 4;
+        auto local = narrow ? k_k1p_local<uint16_t> : k_k1p_local<uint32_t>;
+        uint32_t waves = 1, best = 0;
+        for (uint32_t w = 1; w <= 8; w++) {
+            const uint32_t need = w * per_wave + kStatic;
+            if (need > kLdsPerCu) break;
+            const uint32_t resident = kLdsPerCu / need * w;
+            if (resident > best) { best = resident; waves = w; }
+        }
+        if (const uint32_t v = test_hooks().local_waves) waves = v;
+        uint32_t lds = waves * per_wave;
         if (lds > 60 * 1024) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_k1p_local), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(local), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            if (e != hipSuccess && waves > 1) {                  // a runtime that grants a workgroup less than the CU has: the small workgroups
+                (void)hipGetLastError();
+                waves = per_wave * 2 <= 60 * 1024 ? 2 : 1;
+                lds = waves * per_wave;
+                e = lds > 60 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(local), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))
+                                    : hipSuccess;
+            }
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(k_k1p_local, dim3((pl->total_chunks + 64 * waves - 1) / (64 * waves)), dim3(64 * waves), lds, s, p,
+        hipLaunchKernelGGL(local, dim3((pl->total_chunks + 64 * waves - 1) / (64 * waves)), dim3(64 * waves), lds, s, p,
                            pl->total_chunks, status, lbits, lend, n_retry);
         // How many slices k_k1p_local set aside for the second pass.  Read here, not at the end of the pass: the kernels that
         // follow are launched while the device is still busy with this one's successors only for a moment, where a wait
