@@ -188,7 +188,7 @@ int avr_test_hook_set(const char *name, uint32_t value) {
     if (!strcmp(name, "k1p_force_retry_every")) h.k1p_force_retry_every = value;
     else if (!strcmp(name, "census_stride")) h.census_stride = value;
     else if (!strcmp(name, "chain_lanes")) h.chain_lanes = value;
-    else if (!strcmp(name, "k1_form_norm")) h.k1_form_norm = value;
+    else if (!strcmp(name, "k1_form_ref")) h.k1_form_ref = value;
     else if (!strcmp(name, "k1_emit_lds")) h.k1_emit_lds = value;
     else if (!strcmp(name, "k1_path")) h.k1_path = value;
     else if (!strcmp(name, "no_dense")) h.no_dense = value;

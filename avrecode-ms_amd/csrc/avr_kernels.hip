@@ -30,6 +30,7 @@
 #include "avr_coder.h"
 #include "avr_div.h"
 #include "avr_internal.h"
+#include "avr_k1p.h"
 #include "avr_synth.h"
 #include "avr_tables.h"
 
@@ -116,25 +117,37 @@ struct CabacLaneN {
         R = 510; L2 = 0; sp = -7;                                // range 510 << 22 = 0x7F800000 (cabac_code.h:30)
         e.init(0x7F800000u, out, capacity);
     }
-    __device__ __forceinline__ void bin(uint32_t rec, uint32_t off, const uint2 *tab, uint8_t *st_lane) {
+    // tabn[(state << 1) | bin]: the entry of avr_k1p.h's CodeEntryC -- { the state's LPS ranges, the side as a mask, what the bin
+    // adds to low as a factor of range - rLPS, bypass - 23 } -- with the successor state in the factor's top byte, which the 24-bit
+    // multiply does not see (norm_entry() below)
+    __device__ __forceinline__ void bin(uint32_t rec, uint32_t off, const uint4 *tabn, uint8_t *st_lane) {
         uint8_t *spb = st_lane + off;
         uint32_t s = *spb;
         asm volatile("" : "+v"(s));                              // see CabacLane::bin
-        uint2 ent = tab[s];
+        uint4 ent = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(tabn) + ((s << 5) | ((rec & 1u) << 4)));
         asm volatile("" : "+v"(ent.x), "+v"(ent.y));
-        const uint32_t byp = ent.y >> 31;                                        // cabac_code.h:52-54
-        const uint32_t sym = (rec ^ s) & 1u & ~(ent.y >> 30);                    // the bin is not valMPS (:34); the bin itself for bypass
-        const bool lps = sym & ~byp;
-        const uint32_t rl = (ent.x >> ((R >> 3) & 24u)) & 0xffu;                 // rangeTabLPS[p][quarter] (:39-41); 0 for bypass / no-op
-        const uint32_t rm = R - rl;
-        const uint32_t shm = ((rm >> 8) & 1u) ^ 1u;                              // rm in [128, 511]: one shift iff below 256
-        const uint32_t shl = uint32_t(__builtin_clz(rl | 1u)) - 23u;             // LPS side: range = rLPS, renormalised
-        const uint32_t v = byp ? R : 2u * rm;                                    // what a 1 adds to low, in half units
-        const uint32_t sh0 = lps ? shl : shm, sh = sh0 + byp;
-        L2 = (L2 + (sym ? v : 0u)) << sh;
-        R = (lps ? rl : rm) << sh0;
+        uint32_t v;
+        const uint32_t sh = k1p::step_range_c(k1p::CodeEntryC{ent.x, ent.y, ent.z, ent.w}, &R, &v);
+        L2 = (L2 + v) << sh;
         sp += int32_t(sh);
-        *spb = uint8_t(ent.y >> (8 * sym));                                      // cabac_code.h:43-47
+        *spb = uint8_t(ent.z >> 24);                                             // cabac_code.h:43-47
+    }
+    // the table entry of (state or pseudo state s, bin): see k_cabac_encode for the pseudo states
+    static __device__ uint4 norm_entry(uint32_t s, uint32_t bin) {
+        uint32_t row, sym, next, byp = 0;
+        if (s < 128) {
+            row = d_tables.packed[s][0];
+            sym = (bin ^ s) & 1u;                                                // the bin is not valMPS (cabac_code.h:34)
+            next = (d_tables.packed[s][1] >> (8 * sym)) & 0xffu;
+        } else {
+            const uint32_t t = s - 128;
+            row = t == 2 ? 0x02020202u : 0u;                                     // terminate: LPS range 2, valMPS 0 (:59-61)
+            sym = t == 2 ? bin : 0u;
+            byp = t == 0;                                                        // bypass: the bin itself goes to low (:52-54)
+            next = t == 6 ? 135u : s;
+        }
+        const uint32_t k = byp ? bin : 2u * sym;
+        return make_uint4(row, sym ? ~0u : 0u, k | next << 24, byp - 23u);
     }
     __device__ __forceinline__ void digits() {                   // every digit that is due, oldest first
         while (sp >= 15) {
@@ -239,8 +252,8 @@ constexpr uint32_t kK1Waves = 4;                                 // waves per wo
 // table / index: the dense renumbering of the batch's contexts (k_k1p_densemap), or null: contexts as the caller
 // numbers them.  n_rows: contexts the kernel keeps states for (dense count, or n_states); init_states / final_states
 // rows are n_states wide, in the caller's numbering.
-// FORM: 0 = the coder as cabac_code.h writes it (CabacLane: shipped), 1 = normalised form (CabacLaneN), 2 = digits staged in LDS
-// (CabacLaneS); 1 and 2 are measured variants of the test build.
+// FORM: 1 = normalised form (CabacLaneN: shipped), 0 = the coder as cabac_code.h writes it (CabacLane), 2 = that with its digits
+// staged in LDS (CabacLaneS); 0 and 2 are measured variants of the test build.
 template <bool TILED, int FORM>
 __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
@@ -250,6 +263,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     extern __shared__ uint32_t lds[];                            // per wave: state dwords [(n_rows + 4 + 3) / 4][64]; FORM 2: then 16 x 64 staging slots per wave
     constexpr bool NORM = FORM == 1;
     __shared__ uint2 tab[136];                                   // 128 states + pseudo-states 128..135
+    __shared__ uint4 tabn[NORM ? 272 : 1];                       // the normalised form's: by (state, bin)
     __shared__ uint32_t sel_off[2048];                           // selector -> byte offset of its state in the lane's column (up to 256 rows of 256 bytes, + 3)
 
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -274,6 +288,8 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
         const uint32_t t = threadIdx.x, ps = 128 + t, next = t == 6 ? 135u : ps;
         tab[ps] = make_uint2(t == 2 ? 0x02020202u : 0u, (t == 0 ? 0x80000000u : t >= 4 ? 0x40000000u : 0u) | next | next << 8);
     }
+    if constexpr (NORM)
+        for (uint32_t i = threadIdx.x; i < 272; i += blockDim.x) tabn[i] = CabacLaneN::norm_entry(i >> 1, i & 1u);
     for (uint32_t sel = threadIdx.x; sel < 2048; sel += blockDim.x) {
         uint32_t k;
         if (sel < 1024) {                                        // a context of the slice that has no row: the census missed it
@@ -331,7 +347,8 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t rec = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
-            L.bin(rec, offs[k], tab, st_lane);
+            if constexpr (NORM) L.bin(rec, offs[k], tabn, st_lane);
+            else L.bin(rec, offs[k], tab, st_lane);
             if constexpr (NORM) { if ((k & 3) == 3) L.digits(); }
             if constexpr (FORM == 2) { if (k == 7) L.rows(); }
             const uint32_t t0 = rec == kTerm1 ? c * 8 + k : 0xffffffffu;
@@ -761,10 +778,11 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
         const uint32_t waves = per_wave * kK1Waves <= 60 * 1024 ? kK1Waves : per_wave * 2 <= 60 * 1024 ? 2 : 1;
         const uint32_t lds = waves * per_wave;
         const dim3 grid((n_slices + 64 * waves - 1) / (64 * waves)), block(64 * waves);
-        // test hook k1_form_norm: the coder in normalised form with the digits taken every fourth bin, in step across the wave
-        // (CabacLaneN).  Same bytes; measured on config 5 at the same 2.63 ms per step as the reference's form (what its
-        // emit branch costs, the 64-bit low of the other form costs again), so the form that reads like cabac_code.h stays.
-        const int form = test_hooks().k1_form_norm ? 1 : test_hooks().k1_emit_lds ? 2 : 0;
+        // Shipped: the coder in normalised form with the digits taken every fourth bin, in step across the wave (CabacLaneN) --
+        // since round 3's table entries (avr_k1p.h, CodeEntryC) 31 VALU instructions a bin against the 48 of the form that reads
+        // like cabac_code.h, and 2.44 against 2.55 ms per step on config 5.  Test hooks: k1_form_ref = that form (CabacLane),
+        // k1_emit_lds = it with the digits staged in LDS (CabacLaneS); same bytes all three.
+        const int form = test_hooks().k1_emit_lds ? 2 : test_hooks().k1_form_ref ? 0 : 1;
         auto kern = tiled ? (form == 1 ? k_cabac_encode<true, 1> : form == 2 ? k_cabac_encode<true, 2> : k_cabac_encode<true, 0>)
                           : (form == 1 ? k_cabac_encode<false, 1> : form == 2 ? k_cabac_encode<false, 2> : k_cabac_encode<false, 0>);
         if (lds > 48 * 1024) {

@@ -72,10 +72,10 @@ def test_range_golden_vectors(avr):
 @pytest.mark.parametrize("form", ["ref", "norm", "lds"])
 @pytest.mark.parametrize("n_states", [4, 64, 460, 1024])
 def test_cabac_random_ragged(avr, oracle, n_states, form, hooks):
-    """form: the one-lane-per-slice coder as the reference writes it (shipped), and in normalised form with the digits
-    taken every fourth bin in step across the wave (test hook k1_form_norm: a measured variant, in the test build only)."""
-    if form == "norm":
-        hooks(k1_form_norm=1)
+    """form: the one-lane-per-slice coder in normalised form with the digits taken every fourth bin in step across the wave
+    (shipped), and as the reference writes it (test hook k1_form_ref: a measured variant, in the test build only)."""
+    if form == "ref":
+        hooks(k1_form_ref=1)
     elif form == "lds":                                      # digits staged in LDS, 16-byte rows found by ballot (CabacLaneS): the north star's emitter, measured, not shipped
         hooks(k1_emit_lds=1)
     rng = np.random.default_rng(100 + n_states)

@@ -50,7 +50,8 @@ LANE_CHUNK_READERS = ("k_k1p_local", "k_k1p_replay", "k_k1p_chain", "k_k1p_ctxch
 traffic = {}
 for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches of one step"),
                       (5, "cabac_serial_w5_s1048576", "k_k1_census + k_k1p_densemap + k_cabac_encode<tiled>: all launches of one step"),
-                      ("5lds", "cabac_serial_w5_s1048576_test_hook_k1_emit_lds", "the same with the LDS-row emitter (test build, hook k1_emit_lds): a measured variant")):
+                      ("5lds", "cabac_serial_w5_s1048576_test_hook_k1_emit_lds", "the same with the reference-form coder and the LDS-row emitter (test build, hook k1_emit_lds): a measured variant"),
+                      ("5ref", "cabac_serial_w5_s1048576_test_hook_k1_form_ref", "the same with the coder as cabac_code.h writes it (test build, hook k1_form_ref): round 2's shipped form")):
     if not glob.glob(os.path.join(src, f"w{w}_stats")):
         continue
     shutil.copy(one(f"w{w}_stats/**/*kernel_stats.csv"), os.path.join(dst, f"{rnd}_w{w}_kernel_stats.csv"))

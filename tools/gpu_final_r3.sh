@@ -28,6 +28,7 @@ elif [ "$PART" = b ]; then
   bench w5_k2 --workload 5 --kind range
   bench w3_k2 --workload 3 --kind range --steps 2 --warmup 1 --no-cpu-baseline --no-e2e
   bench w5_lds_rows --workload 5 --no-cpu-baseline --no-e2e --test-hook k1_emit_lds=1
+  bench w5_ref_form --workload 5 --no-cpu-baseline --no-e2e --test-hook k1_form_ref=1
 else
   SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
   prof() { # dir steps args...
@@ -41,6 +42,7 @@ else
   prof w2
   prof w5 --workload 5
   prof w5lds --workload 5 --test-hook k1_emit_lds=1
+  prof w5ref --workload 5 --test-hook k1_form_ref=1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/w2k2_stats -- python3 $R/bench.py --no-cpu-baseline --no-e2e --workload 2 --kind range --steps 3 --warmup 1 > /dev/null 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/w4k2_stats -- python3 $R/bench.py --no-cpu-baseline --no-e2e --workload 4 --kind range --steps 3 --warmup 1 > /dev/null 2>&1
   echo all done
