@@ -83,6 +83,27 @@ def test_chunked_every_context_count_and_length_class(avr, oracle, n_ctx):
         assert fs[i][:n_ctx].tobytes() == want[1], f"final states of slice {i}"
 
 
+@pytest.mark.parametrize("waves", [1, 2, 3, 7, 8])
+def test_chunked_sort_in_workgroups_of_any_size(avr, oracle, hooks, waves):
+    """k_k1p_local sizes its workgroups by what the CU's LDS takes (eight waves with the contexts of a 1080p stream, one with a
+    thousand): every size gives the same bytes (test hook local_waves), with the 16-bit selector table (up to 500 contexts)
+    and the 32-bit one."""
+    hooks(local_waves=waves)
+    rng = np.random.default_rng(2000 + waves)
+    slices = []
+    for i, n_ctx in enumerate([86, 86, 40, 500, 501, 86][:6 if waves < 3 else 3]):     # (501 contexts: 129 KiB a wave, one or two waves only)
+        recs, st = oracle_lib.random_cabac_stream(rng, 9000 + 1500 * i, n_ctx, p_bypass=0.1, terminate=True)
+        slices.append((recs, st, n_ctx))
+    for n_ctx in sorted({c for _, _, c in slices}):
+        group = [(r, s) for r, s, c in slices if c == n_ctx]
+        w = avr.DeviceWorkload.from_host(0, [r for r, _ in group], [s for _, s in group], 0)
+        w.encode_chunked()
+        got, status = w.results()
+        for i, (r, s) in enumerate(group):
+            want = oracle.cabac_encode(r, s)
+            assert status[i] == 0 and got[i] == want[0], f"{n_ctx} contexts, slice {i}"
+
+
 def test_batch_api_from_resolved_codes(avr, oracle):
     """avr_batch_add_slice_codes: the adapter resolves (symbol, *state) itself (cabac_code.h:33, 43-47) and
     ships one byte per bin; no state arrays, half the bytes over PCIe, phase A skipped."""
