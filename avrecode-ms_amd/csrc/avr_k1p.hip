@@ -864,7 +864,6 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
         uint32_t off[8];
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++) off[j] = sel_off[((w[j >> 1] >> ((j & 1) * 16)) >> 1) & 0x7ffu];
-        uint32_t cc[2] = {0, 0};
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++) {
             const uint32_t bin = (w[j >> 1] >> ((j & 1) * 16)) & 1u;
@@ -872,9 +871,10 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
             const uint32_t st = *sp;
             e[j] = info[(st << 1) | bin];
             *sp = uint8_t(e[j].y);
-            cc[j >> 2] |= ((e[j].y >> 8) & 0xffu) << (8 * (j & 3));
         }
-        c0 = cc[0]; c1 = cc[1];
+        // the eight codes (byte 1 of .y) side by side: two byte permutes and an OR per four
+        c0 = __builtin_amdgcn_perm(e[1].y, e[0].y, 0x0c0c0501u) | __builtin_amdgcn_perm(e[3].y, e[2].y, 0x05010c0cu);
+        c1 = __builtin_amdgcn_perm(e[5].y, e[4].y, 0x0c0c0501u) | __builtin_amdgcn_perm(e[7].y, e[6].y, 0x05010c0cu);
     };
     // a slice's records are padded with no-ops to a multiple of 8, its codes to a multiple of 16
     uint32_t i = i0;
