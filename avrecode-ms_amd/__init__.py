@@ -226,7 +226,7 @@ _hooks_lib = None
 def test_hooks(**hooks):
     """FOR tests/ ONLY.  Inside the block, lib() is libavrecode_hip_hooks.so -- the same sources built with
     -DAVR_TEST_HOOKS -- with the named hooks set (csrc/avr_internal.h: k1p_force_retry_every, census_stride,
-    chain_lanes, k1_form_ref, k1_path [1 serial, 2 chunked], no_dense, no_hint, k2p_seg_len, local_waves); all of them keep the bytes exact and
+    chain_lanes, k1_form_ref, k1_path [1 serial, 2 chunked], no_dense, no_hint, k2p_seg_len, local_waves, k2p_wave); all of them keep the bytes exact and
     only force paths that real batches take rarely.  The product library has no such switches."""
     global _lib, _hooks_lib
     if _hooks_lib is None:

@@ -2,6 +2,7 @@
 // per-lane functions are in avr_k2p.h; this file maps them to lanes:
 //
 //   k_k2p_ranges_fp pass 1  lane per slice       the range recurrence (double-precision form); range and bytes emitted at every chunk start
+//   k_k2p_ranges_wave       wave per slice       the same for batches of up to 1 024 slices: the lanes unpack the operands side by side
 //   k_k2p_ranges   pass 1   lane per slice       the same in 64-bit integers: the slices the first form hands over (rare)
 //   k_k2p_zero     pass 2a  lane per chunk       zero the positions of the byte sums that are ADDED into
 //   k_k2p_code     pass 2b  lane per chunk       the coder from (low = 0, noted range); bytes added into 32-bit sums
@@ -244,6 +245,105 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slice
     else if (vmin_hi < kTwo39Hi) status[s] = AVR_SLICE_RETRY_SERIAL;   // the integer form walks it again, from the start
 }
 
+// Pass 1 for batches with no more slices than the chip has SIMDs: a WAVE per slice.  The walk is bound by its instruction
+// count (above), and with a lane per slice a third of it is getting at the operands: addresses out of the record, three
+// data-dependent LDS reads, their waits.  Here the 64 lanes of the slice's wave do that side by side for 64 records at a time
+// -- a lane per record: its table look-ups, then the six doubles into slot `lane` of a ring in LDS -- and the walk reads
+// slot after slot at IMMEDIATE offsets from one base register (every lane the same address: a broadcast): three reads and
+// no address arithmetic per record, about 25 instructions where the lane-per-slice kernel has 31.5.  All lanes walk the same
+// range; lane 0 writes the notes.  Same notes, same statuses, same segments as k_k2p_ranges_fp.
+constexpr uint32_t kRingBins = 64, kRingBytes = kRingBins * 48;
+__global__ __launch_bounds__(64) void k_k2p_ranges_wave(K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
+                                                       uint64_t *fin_range, uint32_t *fin_pos, int32_t *status, uint32_t seg_begin, uint32_t seg_end) {
+    __shared__ TotA tot_a[512];
+    __shared__ TotB tot_b[512];
+    __shared__ PosEntry pos_tab[256];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[2 * kRingBytes];
+    const uint32_t lane = threadIdx.x, s = blockIdx.x;
+    if (s >= n_slices || status[s] != AVR_SLICE_OK) return;     // (the whole wave alike)
+    const uint32_t n = p.n_bins[s], c0 = p.chunk_base[s];
+    const uint32_t n_batches = (n + kRingBins - 1) / kRingBins;
+    const uint32_t b_begin = seg_begin * (kChunk / kRingBins);
+    if (seg_begin && b_begin >= n_batches) return;               // the slice ended in an earlier segment
+    for (uint32_t i = lane; i < 512; i += 64) {
+        const uint32_t d = i >> 1;
+        const double inv = d ? 1.0 / double(d) : 0.0;
+        tot_a[i] = TotA{inv, 0.5 * inv};
+        tot_b[i] = TotB{double(d), 4294967296.0 * inv};
+        if (i < 256) pos_tab[i] = PosEntry{(i & 1u) ? double(d) : -double(d), (i & 1u) ? 0.0 : 1.0};
+    }
+    __syncthreads();
+    const uint16_t *r = p.recs + p.rec_off[s];
+    const uint32_t b_end = uint64_t(seg_end) * (kChunk / kRingBins) < n_batches ? seg_end * (kChunk / kRingBins) : n_batches;
+    RangeFP rg = fp_from_u64(seg_begin ? ck_range[c0 + seg_begin] : kOne);           // arithmetic_code.h:96-97
+    FpConsts K = fp_consts();
+    asm volatile("" : "+s"(K.two32), "+s"(K.inv_two32), "+s"(K.split32), "+s"(K.two51), "+s"(K.two47));
+    uint32_t vmin_hi = 0xffffffffu;
+    uint32_t pos8 = seg_begin ? ck_pos[c0 + seg_begin] * 8u : 0u, high = 0;
+    // a record behind the slice's last is read as 0: { -0, 1 }, a 0 of probability one (k_k2p_ranges_fp)
+    auto load = [&](uint32_t b) -> uint32_t { const uint32_t i = b * kRingBins + lane; return i < n ? uint32_t(r[i]) : 0u; };
+    auto unpack = [&](uint32_t rec, uint32_t half) {             // this lane's record into slot `lane` of ring half `half`
+        high |= rec;
+        const uint32_t pos16 = (rec & 0xffu) << 4, tot16 = pos16 + (((rec >> 8) & 0x7fu) << 5);
+        const TotA ta = *reinterpret_cast<const TotA *>(reinterpret_cast<const uint8_t *>(tot_a) + tot16);
+        const TotB tb = *reinterpret_cast<const TotB *>(reinterpret_cast<const uint8_t *>(tot_b) + tot16);
+        const PosEntry pe = *reinterpret_cast<const PosEntry *>(reinterpret_cast<const uint8_t *>(pos_tab) + pos16);
+        double *slot = reinterpret_cast<double *>(ring + half * kRingBytes + lane * 48);
+        *reinterpret_cast<double2 *>(slot) = make_double2(ta.inv, ta.h);
+        *reinterpret_cast<double2 *>(slot + 2) = make_double2(tb.d, tb.inv32);
+        *reinterpret_cast<double2 *>(slot + 4) = make_double2(pe.ps, pe.nb);
+    };
+    auto note = [&](uint32_t b) {
+        if (lane == 0) { ck_range[c0 + b / (kChunk / kRingBins)] = fp_to_u64(rg); ck_pos[c0 + b / (kChunk / kRingBins)] = pos8 >> 3; }
+    };
+    if (b_begin < b_end) {
+        uint32_t rec1 = load(b_begin + 1);
+        unpack(load(b_begin), b_begin & 1u);
+        for (uint32_t b = b_begin; b < b_end; b++) {
+            const uint32_t rec2 = load(b + 2);                   // two batches ahead of the walk (masked behind the slice's end)
+            if ((b & (kChunk / kRingBins - 1)) == 0) note(b);
+            unpack(rec1, (b + 1) & 1u);                          // the next batch's operands: LDS works in order, the walk below finds its own complete
+            uint32_t base = (b & 1u) * kRingBytes;
+            asm volatile("" : "+v"(base));                       // one base register, the 192 reads at immediate offsets
+            BinFP oa[4], ob[4];
+            auto fetch = [&](uint32_t k0, BinFP o[4]) {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const double2 a = *reinterpret_cast<const double2 *>(ring + base + (k0 + k) * 48);
+                    const double2 c = *reinterpret_cast<const double2 *>(ring + base + (k0 + k) * 48 + 16);
+                    const double2 e = *reinterpret_cast<const double2 *>(ring + base + (k0 + k) * 48 + 32);
+                    o[k] = BinFP{a.x, a.y, c.x, e.x, e.y, c.y};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto walk = [&](const BinFP o[4]) {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) pos8 += range_step_fp(rg, vmin_hi, o[k], K);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            fetch(0, oa);
+#pragma unroll
+            for (uint32_t k0 = 0; k0 < kRingBins; k0 += 8) {
+                fetch(k0 + 4, ob); walk(oa);
+                if (k0 + 8 < kRingBins) fetch(k0 + 8, oa);
+                walk(ob);
+            }
+            rec1 = rec2;
+        }
+    }
+    if (b_end < n_batches) note(b_end);                          // where the next segment picks up
+    else if (lane == 0) {
+        if (n_batches == 0) { ck_range[c0] = kOne; ck_pos[c0] = 0; }
+        fin_range[s] = fp_to_u64(rg);
+        fin_pos[s] = pos8 >> 3;
+    }
+    const bool bad = __any((high & 0x8000u) != 0);
+    if (lane == 0) {
+        if (bad) status[s] = AVR_SLICE_BAD_RECORD;
+        else if (vmin_hi < kTwo39Hi) status[s] = AVR_SLICE_RETRY_SERIAL;   // the integer form walks it again, from the start
+    }
+}
+
 // Which chunk a lane of passes 2a / 2b takes.  seg_len > 0: lane i takes chunk seg_begin + i % seg_len of slice i / seg_len (a
 // segment of every slice, lanes packed); seg_len == 0: lane i takes global chunk i if it lies at or behind seg_begin in its
 // slice (the last, open-ended segment -- and the whole slice when there is only one).  Returns false when there is nothing to do:
@@ -452,7 +552,12 @@ hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
     for (uint32_t k = 0; k < n_seg; k++) {
         const bool open = k + 1 == n_seg;
         const uint32_t begin = k * seg_len, end = open ? 0xffffffffu / kChunk : begin + seg_len;
-        hipLaunchKernelGGL(k_k2p_ranges_fp, slice_grid, dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, begin, end);
+        // a wave per slice while every slice's wave has a SIMD of its own (1 024 of them), a lane per slice beyond
+        const bool wave_per_slice = test_hooks().k2p_wave ? test_hooks().k2p_wave == 1 : n_slices <= 1024;
+        if (wave_per_slice)
+            hipLaunchKernelGGL(k_k2p_ranges_wave, dim3(n_slices), dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, begin, end);
+        else
+            hipLaunchKernelGGL(k_k2p_ranges_fp, slice_grid, dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, begin, end);
         if (side) {
             if ((e = hipEventRecord(side->seg[k], s)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(s2, side->seg[k], 0)) != hipSuccess) return e;

@@ -380,7 +380,7 @@ def main():
                          "kernel": (K1P_KERNELS if path == "chunked" else
                                     "k_k1_census (1-in-16 sample) + k_k1p_densemap + k_cabac_encode<tiled> + its hand-back launch (one step = all of them)")
                          if kind == avr.KIND_CABAC else
-                         ("K2p: k_k2p_ranges_fp (the range recurrence, one lane per slice: the wall) + its idle hand-over + k_k2p_fits + "
+                         ("K2p: k_k2p_ranges_wave (up to 1 024 slices: a wave per slice) or k_k2p_ranges_fp (a lane per slice) -- the range recurrence: the wall -- + its idle hand-over + k_k2p_fits + "
                           "k_k2p_zero + k_k2p_code + k_k2p_finish"
                           if path == "chunked" else "k_range_encode<tiled>"),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,

@@ -388,15 +388,18 @@ def test_chunked_census_sample_second_pass_and_validation(avr, oracle, stride, h
 
 # ------------------------------------------------------------------ K2p: the recoded range coder in three passes
 
+@pytest.mark.parametrize("pass1", ["wave", "lane"])
 @pytest.mark.parametrize("seg_len", [0, 1, 3])
-def test_range_chunked_random_and_extremes(avr, oracle, hooks, seg_len):
+def test_range_chunked_random_and_extremes(avr, oracle, hooks, seg_len, pass1):
     """avr_range_encode_chunked_device against the oracle: ragged lengths around the chunk size, adaptive and fixed
     estimators, certain bins (no output for thousands of bins), the most lopsided estimators, empty slices, a record with
     neg 0 (the range collapses to a few bits: the double-precision walk hands the slice to the integer one), and a
     zero-probability bin in the middle of a slice (status, like arithmetic_code.h:116-118).  seg_len 1 / 3 (test hook): the
-    passes run segment by segment on two streams, as they do for long slices, with a segment boundary at every (third) chunk."""
-    if seg_len:
-        hooks(k2p_seg_len=seg_len)
+    passes run segment by segment on two streams, as they do for long slices, with a segment boundary at every (third) chunk.
+    pass1: the range recurrence by a wave per slice (what a batch of up to 1 024 slices gets) and by a lane per slice (test hook
+    k2p_wave=2: what larger batches get)."""
+    lane = {"k2p_wave": 2} if pass1 == "lane" else {}
+    hooks(k2p_seg_len=seg_len, **lane)
     rng = np.random.default_rng(17)
     def rec(b, pos, neg):
         return b | (pos << 1) | (neg << 8)
@@ -418,7 +421,7 @@ def test_range_chunked_random_and_extremes(avr, oracle, hooks, seg_len):
         assert st == 0 and status[i] == 0 and got[i] == want, f"slice {i} n={len(r)}"
     assert status[-1] == avr.SLICE_ZERO_PROB and oracle.range_encode(zero)[1] == 1
     # the same slices through the batch API (which picks the three-pass form by the batch's shape: force it)
-    hooks(k2p_seg_len=seg_len, k1_path=2)
+    hooks(k2p_seg_len=seg_len, k1_path=2, **lane)
     with avr.Batch(0, len(slices), sum(len(r) for r in slices) + 8) as b:
         for r in slices:
             b.add_slice_range(r)
