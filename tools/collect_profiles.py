@@ -22,7 +22,7 @@ def one(pattern):
     hits = glob.glob(os.path.join(src, pattern), recursive=True)
     if not hits:
         raise SystemExit(f"missing {pattern} under {src}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)                       # (a directory may hold an earlier run's file too: the latest)
 
 
 def short(name):
@@ -93,7 +93,7 @@ json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), inde
 for d in ("w2k2", "w4k2"):                               # kernel stats of the compress direction
     hits = glob.glob(os.path.join(src, f"{d}_stats/**/*kernel_stats.csv"), recursive=True)
     if hits:
-        shutil.copy(hits[0], os.path.join(dst, f"{rnd}_{d}_kernel_stats.csv"))
+        shutil.copy(max(hits, key=os.path.getmtime), os.path.join(dst, f"{rnd}_{d}_kernel_stats.csv"))
 benches = sorted(os.path.basename(p)[len("bench_"):-len(".json")] for p in glob.glob(os.path.join(src, "bench_*.json")))
 for b in benches:
     shutil.copy(os.path.join(src, f"bench_{b}.json"), os.path.join(dst, f"{rnd}_bench_{b}.json"))
