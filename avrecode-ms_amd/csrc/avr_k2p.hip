@@ -146,8 +146,9 @@ struct PosEntry { double ps, nb; };                       // by the record's low
 // The walk is launched in SEGMENTS of chunks [seg_begin, seg_end) of every slice (a lane picks up its range and byte count from
 // the note of chunk seg_begin, which the segment before it left): pass 2 of a segment then runs on a second stream while pass 1
 // walks the next one -- pass 1 keeps a handful of the chip's 1 024 SIMDs busy, pass 2 takes the rest (launch_k2p).
-__global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
-                                                     uint64_t *fin_range, uint32_t *fin_pos, int32_t *status, uint32_t seg_begin, uint32_t seg_end) {
+// (block: which 64 slices; long_chunks: slices of that many chunks or more are not this kernel's -- k_k2p_ranges_hybrid)
+__device__ __forceinline__ void ranges_fp_body(uint32_t block, uint32_t long_chunks, K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
+                                               uint64_t *fin_range, uint32_t *fin_pos, int32_t *status, uint32_t seg_begin, uint32_t seg_end) {
     __shared__ TotA tot_a[512];
     __shared__ TotB tot_b[512];
     __shared__ PosEntry pos_tab[256];
@@ -159,9 +160,10 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slice
         if (i < 256) pos_tab[i] = PosEntry{(i & 1u) ? double(d) : -double(d), (i & 1u) ? 0.0 : 1.0};
     }
     __syncthreads();
-    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t s = block * 64 + threadIdx.x;
     if (s >= n_slices || status[s] != AVR_SLICE_OK) return;
     const uint32_t n = p.n_bins[s], c0 = p.chunk_base[s];
+    if (p.chunk_base[s + 1] - c0 >= long_chunks) return;
     const U4 *r = reinterpret_cast<const U4 *>(p.recs + p.rec_off[s]);
     const uint32_t n_groups = (n + 7) >> 3, last = n_groups ? n_groups - 1 : 0;
     const uint32_t g_begin = seg_begin * (kChunk / 8);
@@ -253,15 +255,16 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slice
 // no address arithmetic per record, about 25 instructions where the lane-per-slice kernel has 31.5.  All lanes walk the same
 // range; lane 0 writes the notes.  Same notes, same statuses, same segments as k_k2p_ranges_fp.
 constexpr uint32_t kRingBins = 64, kRingBytes = kRingBins * 48;
-__global__ __launch_bounds__(64) void k_k2p_ranges_wave(K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
-                                                       uint64_t *fin_range, uint32_t *fin_pos, int32_t *status, uint32_t seg_begin, uint32_t seg_end) {
+__device__ __forceinline__ void ranges_wave_body(uint32_t s, uint32_t long_chunks, K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
+                                                 uint64_t *fin_range, uint32_t *fin_pos, int32_t *status, uint32_t seg_begin, uint32_t seg_end) {
     __shared__ TotA tot_a[512];
     __shared__ TotB tot_b[512];
     __shared__ PosEntry pos_tab[256];
     __shared__ __attribute__((aligned(16))) uint8_t ring[2 * kRingBytes];
-    const uint32_t lane = threadIdx.x, s = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
     if (s >= n_slices || status[s] != AVR_SLICE_OK) return;     // (the whole wave alike)
     const uint32_t n = p.n_bins[s], c0 = p.chunk_base[s];
+    if (p.chunk_base[s + 1] - c0 < long_chunks) return;          // (k_k2p_ranges_hybrid: a lane's)
     const uint32_t n_batches = (n + kRingBins - 1) / kRingBins;
     const uint32_t b_begin = seg_begin * (kChunk / kRingBins);
     if (seg_begin && b_begin >= n_batches) return;               // the slice ended in an earlier segment
@@ -342,6 +345,52 @@ __global__ __launch_bounds__(64) void k_k2p_ranges_wave(K2Plan p, uint32_t n_sli
         if (bad) status[s] = AVR_SLICE_BAD_RECORD;
         else if (vmin_hi < kTwo39Hi) status[s] = AVR_SLICE_RETRY_SERIAL;   // the integer form walks it again, from the start
     }
+}
+
+__global__ __launch_bounds__(64) void k_k2p_ranges_fp(K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
+                                                     uint64_t *fin_range, uint32_t *fin_pos, int32_t *status, uint32_t seg_begin, uint32_t seg_end) {
+    ranges_fp_body(blockIdx.x, 0xffffffffu, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, seg_begin, seg_end);
+}
+__global__ __launch_bounds__(64) void k_k2p_ranges_wave(K2Plan p, uint32_t n_slices, uint64_t *ck_range, uint32_t *ck_pos,
+                                                       uint64_t *fin_range, uint32_t *fin_pos, int32_t *status, uint32_t seg_begin, uint32_t seg_end) {
+    ranges_wave_body(blockIdx.x, 0u, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, seg_begin, seg_end);
+}
+// Both in one launch, for a ragged batch of more slices than SIMDs: a lane per slice packs 64 slices into a wave and leaves
+// most of the chip idle, and the step takes as long as the longest slice -- so the longest slices, as many as there are SIMDs
+// left over, get a wave each (blocks lane_blocks .. of the grid), which walks 13 % faster.  *long_chunks (k_k2p_threshold) is
+// the chunk count from which a slice counts as long.
+__global__ __launch_bounds__(64) void k_k2p_ranges_hybrid(uint32_t lane_blocks, const uint32_t *long_chunks, K2Plan p, uint32_t n_slices,
+                                                         uint64_t *ck_range, uint32_t *ck_pos, uint64_t *fin_range, uint32_t *fin_pos,
+                                                         int32_t *status, uint32_t seg_begin, uint32_t seg_end) {
+    const uint32_t t = long_chunks[0];                           // long_chunks[1]: how many long slices, [2 ..]: which
+    if (blockIdx.x < lane_blocks) ranges_fp_body(blockIdx.x, t, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, seg_begin, seg_end);
+    else if (blockIdx.x - lane_blocks < long_chunks[1])
+        ranges_wave_body(long_chunks[2 + blockIdx.x - lane_blocks], t, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, seg_begin, seg_end);
+}
+// long_chunks[0] = the smallest power of two 2^k such that at most max_long slices have 2^k chunks or more (0xffffffff: there is
+// none), [1] = how many slices that is, [2 ..] = those slices.
+__global__ __launch_bounds__(1024) void k_k2p_threshold(const uint32_t *chunk_base, uint32_t n_slices, uint32_t max_long, uint32_t *long_chunks) {
+    __shared__ uint32_t hist[33];                                // hist[b]: slices whose chunk count has b significant bits
+    __shared__ uint32_t thr, count;
+    if (threadIdx.x < 33) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < n_slices; s += 1024) atomicAdd(&hist[32 - __clz(chunk_base[s + 1] - chunk_base[s])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0xffffffffu, above = 0;
+        for (int b = 32; b >= 1; b--) {                          // slices of 2^(b-1) chunks or more: those with b or more significant bits
+            above += hist[b];
+            if (above > max_long) break;
+            t = 1u << (b - 1);
+        }
+        long_chunks[0] = thr = t;
+        count = 0;
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < n_slices; s += 1024)
+        if (chunk_base[s + 1] - chunk_base[s] >= thr) long_chunks[2 + atomicAdd(&count, 1u)] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) long_chunks[1] = count;
 }
 
 // Which chunk a lane of passes 2a / 2b takes.  seg_len > 0: lane i takes chunk seg_begin + i % seg_len of slice i / seg_len (a
@@ -498,7 +547,7 @@ inline uint64_t up256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 
 // workspace: ck_range, ck_pos per chunk; fin_range, fin_pos per slice; 32-bit sums per output byte position
 size_t k2p_workspace_bytes(size_t n_slices, uint32_t total_chunks, uint64_t out_total) {
-    return size_t(up256(uint64_t(total_chunks) * 8) + up256(uint64_t(total_chunks) * 4) + up256(n_slices * 8) + up256(n_slices * 4) +
+    return size_t(up256(uint64_t(total_chunks) * 8) + up256(uint64_t(total_chunks) * 4) + up256(n_slices * 8) + up256(n_slices * 4) + 4096 +
                   up256(out_total * 4 + 64));
 }
 
@@ -537,6 +586,7 @@ hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
     uint32_t *ck_pos = reinterpret_cast<uint32_t *>(w);      w += up256(uint64_t(total_chunks) * 4);
     uint64_t *fin_range = reinterpret_cast<uint64_t *>(w);   w += up256(uint64_t(n_slices) * 8);
     uint32_t *fin_pos = reinterpret_cast<uint32_t *>(w);     w += up256(uint64_t(n_slices) * 4);
+    uint32_t *long_chunks = reinterpret_cast<uint32_t *>(w); w += 4096;     // the hybrid pass 1's threshold, count and list of long slices (at most 1 022)
     uint32_t *S = reinterpret_cast<uint32_t *>(w);
     const K2Plan p{recs, rec_off, n_bins, chunk_base, chunk_slice, out_off};
     const dim3 slice_grid((n_slices + 63) / 64), chunk_grid((total_chunks + 255) / 256);
@@ -549,13 +599,19 @@ hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
     hipError_t e;
     if (n_seg > 1 && (e = side_stream(s, &side)) != hipSuccess) return e;
     hipStream_t s2 = side ? side->side : s;
+    // a wave per slice while every slice's wave has a SIMD of its own (1 024 of them); beyond, a lane per slice and -- while the
+    // lanes' waves leave SIMDs over -- a wave each for the longest slices (test hook k2p_wave: 1 / 2 = the one / the other for all)
+    constexpr uint32_t kSimds = 1024;
+    const uint32_t form = test_hooks().k2p_wave ? test_hooks().k2p_wave : n_slices <= kSimds ? 1u : slice_grid.x + 64 <= kSimds ? 3u : 2u;
+    if (form == 3) hipLaunchKernelGGL(k_k2p_threshold, dim3(1), dim3(1024), 0, s, chunk_base, n_slices, kSimds - slice_grid.x, long_chunks);
     for (uint32_t k = 0; k < n_seg; k++) {
         const bool open = k + 1 == n_seg;
         const uint32_t begin = k * seg_len, end = open ? 0xffffffffu / kChunk : begin + seg_len;
-        // a wave per slice while every slice's wave has a SIMD of its own (1 024 of them), a lane per slice beyond
-        const bool wave_per_slice = test_hooks().k2p_wave ? test_hooks().k2p_wave == 1 : n_slices <= 1024;
-        if (wave_per_slice)
+        if (form == 1)
             hipLaunchKernelGGL(k_k2p_ranges_wave, dim3(n_slices), dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, begin, end);
+        else if (form == 3)
+            hipLaunchKernelGGL(k_k2p_ranges_hybrid, dim3(kSimds), dim3(64), 0, s, slice_grid.x, long_chunks, p, n_slices, ck_range, ck_pos,
+                               fin_range, fin_pos, status, begin, end);
         else
             hipLaunchKernelGGL(k_k2p_ranges_fp, slice_grid, dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, begin, end);
         if (side) {

@@ -388,7 +388,7 @@ def test_chunked_census_sample_second_pass_and_validation(avr, oracle, stride, h
 
 # ------------------------------------------------------------------ K2p: the recoded range coder in three passes
 
-@pytest.mark.parametrize("pass1", ["wave", "lane"])
+@pytest.mark.parametrize("pass1", ["wave", "lane", "both"])
 @pytest.mark.parametrize("seg_len", [0, 1, 3])
 def test_range_chunked_random_and_extremes(avr, oracle, hooks, seg_len, pass1):
     """avr_range_encode_chunked_device against the oracle: ragged lengths around the chunk size, adaptive and fixed
@@ -396,9 +396,10 @@ def test_range_chunked_random_and_extremes(avr, oracle, hooks, seg_len, pass1):
     neg 0 (the range collapses to a few bits: the double-precision walk hands the slice to the integer one), and a
     zero-probability bin in the middle of a slice (status, like arithmetic_code.h:116-118).  seg_len 1 / 3 (test hook): the
     passes run segment by segment on two streams, as they do for long slices, with a segment boundary at every (third) chunk.
-    pass1: the range recurrence by a wave per slice (what a batch of up to 1 024 slices gets) and by a lane per slice (test hook
-    k2p_wave=2: what larger batches get)."""
-    lane = {"k2p_wave": 2} if pass1 == "lane" else {}
+    pass1: the range recurrence by a wave per slice (what a batch of up to 1 024 slices gets), by a lane per slice (test hook
+    k2p_wave=2) and by both in one launch, the longest slices a wave each (3: what larger batches get; here every slice is long --
+    the full-size run of config 3 below has both kinds)."""
+    lane = {"k2p_wave": 2} if pass1 == "lane" else {"k2p_wave": 3} if pass1 == "both" else {}
     hooks(k2p_seg_len=seg_len, **lane)
     rng = np.random.default_rng(17)
     def rec(b, pos, neg):
