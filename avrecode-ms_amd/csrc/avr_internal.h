@@ -37,7 +37,7 @@ struct TestHooks {
     uint32_t census_stride;          // sampling stride of both census kernels (0 = the built-in 16)
     uint32_t chain_lanes;            // lanes per wave of k_k1p_ctxchain (0 = by batch shape)
     uint32_t k1_form_ref;           // one-lane-per-slice K1 as cabac_code.h writes the coder (CabacLane) instead of the shipped normalised form
-    uint32_t k1_emit_lds;            // one-lane-per-slice K1 with its digits staged in LDS and stored in 16-byte rows (CabacLaneS)
+    uint32_t k1_emit_lds;            // one-lane-per-slice K1 with its digits staged in LDS and stored in 16-byte rows: 1 = on the reference-style form (CabacLaneS), 2 = on the shipped one (CabacLaneNS)
     uint32_t k1_path, no_dense, no_hint;   // the environment switches above, settable per test (non-zero wins over env())
     uint32_t chain_segments;         // K1p: the context chains in segments whatever the batch's size
     uint32_t chain_whole;            // K1p: every context chain start to end (k_k1p_ctxchain alone), no segments

@@ -246,6 +246,73 @@ struct CabacLaneS {
     }
 };
 
+// The normalised form with CabacLaneS's emitter: the due digits go into the lane's staging column, whole 16-byte rows out
+// by one ballot per eight bins.  The normalised form waits where the other one computes (62 % of its wave-cycles on config 5);
+// if it waited for its own output -- 8-byte stores of a lane's own, ten times the bytes in 64-byte requests -- this would be
+// the faster kernel.  It is not: 2.88 against 2.49 ms on config 5.  A measured variant (test hook k1_emit_lds=2).
+struct CabacLaneNS : CabacLaneN {
+    uint32_t *stage;                                             // this lane's column: slot j at stage[64 j]
+    uint32_t cnt, flushed;                                       // digits produced / stored (flushed: a multiple of 8)
+
+    __device__ __forceinline__ void init(uint8_t *out, uint32_t capacity, uint32_t *column) {
+        CabacLaneN::init(out, capacity);
+        stage = column; cnt = flushed = 0;
+    }
+    __device__ void carry() {                                    // arithmetic_code.h:154-157: into the staged digits, then the stored bytes
+        for (uint32_t i = cnt; i > flushed;) {
+            i--;
+            const uint32_t d = (stage[64 * (i & 15u)] + 1u) & 0xffffu;
+            stage[64 * (i & 15u)] = d;
+            if (d) return;
+        }
+        uint32_t p = flushed * 2;
+        if (p > e.w.cap) return;
+        while (p > 0) {
+            p--;
+            const uint32_t b = uint32_t(e.w.base[p]) + 1u;
+            e.w.base[p] = uint8_t(b);
+            if (b <= 0xffu) break;
+        }
+    }
+    __device__ __forceinline__ void digits() {                   // every digit that is due, oldest first (at most 5 per eight bins: 16 slots do)
+        while (sp >= 15) {
+            uint32_t d = uint32_t(L2 >> (sp + 1));
+            L2 &= (uint64_t(2) << sp) - 1;
+            if (__builtin_expect(d >> 16, 0)) { carry(); d &= 0xffffu; }
+            stage[64 * (cnt & 15u)] = d;
+            cnt++;
+            sp -= 16;
+        }
+    }
+    __device__ __forceinline__ void rows() {                     // after every eight bins
+        const bool ready = cnt - flushed >= 8u;
+        if (__ballot(ready)) {
+            if (ready) {
+                uint32_t d[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) d[j] = stage[64 * ((flushed + j) & 15u)];
+                Row16 v;                                         // digits most significant byte first (arithmetic_code.h:184-190)
+                v.x = __builtin_bswap32(d[0] << 16 | d[1]); v.y = __builtin_bswap32(d[2] << 16 | d[3]);
+                v.z = __builtin_bswap32(d[4] << 16 | d[5]); v.w = __builtin_bswap32(d[6] << 16 | d[7]);
+                if (flushed * 2 + 16 <= e.w.cap) *reinterpret_cast<Row16 *>(e.w.base + flushed * 2) = v;
+                flushed += 8;
+            }
+        }
+    }
+    __device__ void finish() {                                   // back to the reference's (low, range); what is staged through the byte writer; its finish()
+        digits();
+        const uint32_t ex = uint32_t(15 - sp);                   // 1 .. 22
+        uint64_t low = L2 << (ex - 1);
+        if (low >= CabacEncoder::kOne) { carry(); low -= CabacEncoder::kOne; }
+        e.low = uint32_t(low);
+        e.range = R << ex;
+        e.w.n = flushed * 2;
+        e.w.acc = 0;
+        for (uint32_t i = flushed; i < cnt; i++) e.w.put16_even(stage[64 * (i & 15u)]);
+        e.finish();
+    }
+};
+
 constexpr uint32_t kCensusStride = 16;                           // the one-lane-per-slice kernel renumbers from a 1-in-16 sample
 constexpr uint32_t kK1Waves = 4;                                 // waves per workgroup (fewer when the state rows are large): they share the two tables
 
@@ -253,7 +320,7 @@ constexpr uint32_t kK1Waves = 4;                                 // waves per wo
 // numbers them.  n_rows: contexts the kernel keeps states for (dense count, or n_states); init_states / final_states
 // rows are n_states wide, in the caller's numbering.
 // FORM: 1 = normalised form (CabacLaneN: shipped), 0 = the coder as cabac_code.h writes it (CabacLane), 2 = that with its digits
-// staged in LDS (CabacLaneS); 0 and 2 are measured variants of the test build.
+// staged in LDS (CabacLaneS), 3 = the normalised form with them (CabacLaneNS); 0, 2 and 3 are measured variants of the test build.
 template <bool TILED, int FORM>
 __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
@@ -261,7 +328,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
     uint8_t *final_states, int32_t want_status) {
     extern __shared__ uint32_t lds[];                            // per wave: state dwords [(n_rows + 4 + 3) / 4][64]; FORM 2: then 16 x 64 staging slots per wave
-    constexpr bool NORM = FORM == 1;
+    constexpr bool NORM = FORM == 1 || FORM == 3;
     __shared__ uint2 tab[136];                                   // 128 states + pseudo-states 128..135
     __shared__ uint4 tabn[NORM ? 272 : 1];                       // the normalised form's: by (state, bin)
     __shared__ uint32_t sel_off[2048];                           // selector -> byte offset of its state in the lane's column (up to 256 rows of 256 bytes, + 3)
@@ -321,11 +388,12 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
     }
     __syncthreads();
 
-    typename std::conditional<NORM, CabacLaneN, typename std::conditional<FORM == 2, CabacLaneS, CabacLane>::type>::type L;
+    typename std::conditional<FORM == 3, CabacLaneNS, typename std::conditional<FORM == 1, CabacLaneN,
+        typename std::conditional<FORM == 2, CabacLaneS, CabacLane>::type>::type>::type L;
     const uint64_t o0 = in_range ? out_off[slice] : 0;
     const uint32_t cap = in_range ? uint32_t(out_off[slice + 1] - o0) : 0;
-    if constexpr (NORM) L.init(out + o0, cap);
-    else if constexpr (FORM == 2) L.init(out + o0, cap, lds + (blockDim.x >> 6) * rows4 * 64 + wv * 1024 + lane);
+    if constexpr (FORM == 1) L.init(out + o0, cap);
+    else if constexpr (FORM == 2 || FORM == 3) L.init(out + o0, cap, lds + (blockDim.x >> 6) * rows4 * 64 + wv * 1024 + lane);
     else L.e.init(0x7F800000u, out + o0, cap);                   // cabac_code.h:30
 
     const ChunkSource<TILED> src(recs, off, in_range ? g : 0, slice);
@@ -350,7 +418,7 @@ __global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
             if constexpr (NORM) L.bin(rec, offs[k], tabn, st_lane);
             else L.bin(rec, offs[k], tab, st_lane);
             if constexpr (NORM) { if ((k & 3) == 3) L.digits(); }
-            if constexpr (FORM == 2) { if (k == 7) L.rows(); }
+            if constexpr (FORM == 2 || FORM == 3) { if (k == 7) L.rows(); }
             const uint32_t t0 = rec == kTerm1 ? c * 8 + k : 0xffffffffu;
             term_at = term_at < t0 ? term_at : t0;
         }
@@ -774,17 +842,17 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
             return err;                                          // contexts without bins keep their state
     }
     auto launch = [&](uint32_t rows, const uint16_t *tb, const uint16_t *ix, int32_t want) -> hipError_t {
-        const uint32_t per_wave = ((rows + 4 + 3) / 4) * 256 + (test_hooks().k1_emit_lds ? 4096u : 0u);     // (+ the staging slots of FORM 2)
+        const uint32_t per_wave = ((rows + 4 + 3) / 4) * 256 + (test_hooks().k1_emit_lds ? 4096u : 0u);     // (+ the staging slots of FORMs 2, 3)
         const uint32_t waves = per_wave * kK1Waves <= 60 * 1024 ? kK1Waves : per_wave * 2 <= 60 * 1024 ? 2 : 1;
         const uint32_t lds = waves * per_wave;
         const dim3 grid((n_slices + 64 * waves - 1) / (64 * waves)), block(64 * waves);
         // Shipped: the coder in normalised form with the digits taken every fourth bin, in step across the wave (CabacLaneN) --
         // since round 3's table entries (avr_k1p.h, CodeEntryC) 31 VALU instructions a bin against the 48 of the form that reads
         // like cabac_code.h, and 2.44 against 2.55 ms per step on config 5.  Test hooks: k1_form_ref = that form (CabacLane),
-        // k1_emit_lds = it with the digits staged in LDS (CabacLaneS); same bytes all three.
-        const int form = test_hooks().k1_emit_lds ? 2 : test_hooks().k1_form_ref ? 0 : 1;
-        auto kern = tiled ? (form == 1 ? k_cabac_encode<true, 1> : form == 2 ? k_cabac_encode<true, 2> : k_cabac_encode<true, 0>)
-                          : (form == 1 ? k_cabac_encode<false, 1> : form == 2 ? k_cabac_encode<false, 2> : k_cabac_encode<false, 0>);
+        // k1_emit_lds = 1: it with the digits staged in LDS (CabacLaneS), 2: the shipped form with them (CabacLaneNS); same bytes all.
+        const int form = test_hooks().k1_emit_lds ? (test_hooks().k1_emit_lds == 2 ? 3 : 2) : test_hooks().k1_form_ref ? 0 : 1;
+        auto kern = tiled ? (form == 1 ? k_cabac_encode<true, 1> : form == 2 ? k_cabac_encode<true, 2> : form == 3 ? k_cabac_encode<true, 3> : k_cabac_encode<true, 0>)
+                          : (form == 1 ? k_cabac_encode<false, 1> : form == 2 ? k_cabac_encode<false, 2> : form == 3 ? k_cabac_encode<false, 3> : k_cabac_encode<false, 0>);
         if (lds > 48 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
             if (e != hipSuccess) return e;

@@ -69,14 +69,16 @@ def test_range_golden_vectors(avr):
 
 # ------------------------------------------------------------------ random, ragged, edge cases
 
-@pytest.mark.parametrize("form", ["ref", "norm", "lds"])
+@pytest.mark.parametrize("form", ["ref", "norm", "lds", "ref-lds"])
 @pytest.mark.parametrize("n_states", [4, 64, 460, 1024])
 def test_cabac_random_ragged(avr, oracle, n_states, form, hooks):
     """form: the one-lane-per-slice coder in normalised form with the digits taken every fourth bin in step across the wave
     (shipped), and as the reference writes it (test hook k1_form_ref: a measured variant, in the test build only)."""
     if form == "ref":
         hooks(k1_form_ref=1)
-    elif form == "lds":                                      # digits staged in LDS, 16-byte rows found by ballot (CabacLaneS): the north star's emitter, measured, not shipped
+    elif form == "lds":                                      # digits staged in LDS, 16-byte rows found by ballot: the north star's emitter on the shipped form (CabacLaneNS)
+        hooks(k1_emit_lds=2)
+    elif form == "ref-lds":                                  # ... and on the form as the reference writes it (CabacLaneS)
         hooks(k1_emit_lds=1)
     rng = np.random.default_rng(100 + n_states)
     slices = []
