@@ -29,6 +29,7 @@ elif [ "$PART" = b ]; then
   bench w3_k2 --workload 3 --kind range --steps 2 --warmup 1 --no-cpu-baseline --no-e2e
   bench w5_lds_rows --workload 5 --no-cpu-baseline --no-e2e --test-hook k1_emit_lds=1
   bench w5_ref_form --workload 5 --no-cpu-baseline --no-e2e --test-hook k1_form_ref=1
+  bench w5_norm_lds_rows --workload 5 --no-cpu-baseline --no-e2e --test-hook k1_emit_lds=2
 else
   SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
   prof() { # dir steps args...
