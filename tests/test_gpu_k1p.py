@@ -432,6 +432,24 @@ def test_range_chunked_random_and_extremes(avr, oracle, hooks, seg_len, pass1):
         assert b.get(len(slices) - 1)[1] == avr.SLICE_ZERO_PROB
 
 
+def test_range_chunked_ragged_batch_long_slices_by_waves(avr, oracle):
+    """More slices than SIMDs, a few of them far longer than the rest: pass 1 walks a lane per slice and, in the same launch, the
+    longest slices by a wave each (k_k2p_ranges_hybrid; which ones: k_k2p_threshold's power-of-two cut).  Every slice against the
+    oracle -- the long ones, the ones just below the cut, empty ones."""
+    rng = np.random.default_rng(23)
+    lengths = [int(x) for x in rng.integers(0, 2500, 1100)]
+    for i, n in zip((3, 97, 500, 777, 1023, 1099), (150000, 70000, 33000, 16384 + 5, 8191, 65536)):
+        lengths[i] = n
+    lengths[10] = 0
+    slices = [oracle_lib.random_range_stream(rng, n, adaptive=bool(i % 3)) for i, n in enumerate(lengths)]
+    w = avr.DeviceWorkload.from_host(1, slices, None, 0)
+    w.encode_chunked()
+    got, status = w.results()
+    for i, r in enumerate(slices):
+        want, st = oracle.range_encode(r)
+        assert st == 0 and status[i] == 0 and got[i] == want, f"slice {i} n={len(r)}"
+
+
 def test_range_chunked_config2_cut_equals_the_serial_kernel(avr, oracle):
     """A 24-slice cut of BASELINE.json's configs[1] in the compress direction: the three-pass path and the one-lane-per-slice
     kernel give the same bytes, and sampled slices equal the oracle's."""
