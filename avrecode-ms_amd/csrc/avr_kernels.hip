@@ -314,7 +314,8 @@ struct CabacLaneNS : CabacLaneN {
 };
 
 constexpr uint32_t kCensusStride = 16;                           // the one-lane-per-slice kernel renumbers from a 1-in-16 sample
-constexpr uint32_t kK1Waves = 4;                                 // waves per workgroup (fewer when the state rows are large): they share the two tables
+constexpr uint32_t kK1Waves = 8;                                 // waves per workgroup (fewer when the state rows are large): they share the two tables
+constexpr uint32_t kK1MaxWaves = 16;
 
 // table / index: the dense renumbering of the batch's contexts (k_k1p_densemap), or null: contexts as the caller
 // numbers them.  n_rows: contexts the kernel keeps states for (dense count, or n_states); init_states / final_states
@@ -322,7 +323,7 @@ constexpr uint32_t kK1Waves = 4;                                 // waves per wo
 // FORM: 1 = normalised form (CabacLaneN: shipped), 0 = the coder as cabac_code.h writes it (CabacLane), 2 = that with its digits
 // staged in LDS (CabacLaneS), 3 = the normalised form with them (CabacLaneNS); 0, 2 and 3 are measured variants of the test build.
 template <bool TILED, int FORM>
-__global__ __launch_bounds__(64 * kK1Waves) void k_cabac_encode(
+__global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
     const void *recs, const uint64_t *off, const uint32_t *n_bins, const uint32_t *order,
     uint32_t n_slices, const uint8_t *init_states, uint32_t n_states, const uint16_t *table, const uint16_t *index, uint32_t n_rows,
     uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
@@ -843,7 +844,9 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
     }
     auto launch = [&](uint32_t rows, const uint16_t *tb, const uint16_t *ix, int32_t want) -> hipError_t {
         const uint32_t per_wave = ((rows + 4 + 3) / 4) * 256 + (test_hooks().k1_emit_lds ? 4096u : 0u);     // (+ the staging slots of FORMs 2, 3)
-        const uint32_t waves = per_wave * kK1Waves <= 60 * 1024 ? kK1Waves : per_wave * 2 <= 60 * 1024 ? 2 : 1;
+        uint32_t want_waves = test_hooks().k1_waves ? test_hooks().k1_waves : kK1Waves;
+        if (want_waves > kK1MaxWaves) want_waves = kK1MaxWaves;
+        const uint32_t waves = per_wave * want_waves <= 60 * 1024 ? want_waves : per_wave * 4 <= 60 * 1024 ? 4 : per_wave * 2 <= 60 * 1024 ? 2 : 1;
         const uint32_t lds = waves * per_wave;
         const dim3 grid((n_slices + 64 * waves - 1) / (64 * waves)), block(64 * waves);
         // Shipped: the coder in normalised form with the digits taken every fourth bin, in step across the wave (CabacLaneN) --

@@ -230,6 +230,27 @@ def e2e_block(avr, workload, kind, n_slices, first_slice, device, rounds=12, obj
             "h2d_ms_alone": tm["h2d_ms"], "note": "PCIe-inclusive; never the bench line's value"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N ...` with no launcher around it: N ranks of this same command line under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1 at a port that is free now).  Returns the child's exit code; rank 0's JSON
+    line goes to this process's stdout, everything else the ranks print to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for out_line in child.stdout:                            # only rank 0 prints to stdout: the one JSON line
+        sys.stdout.write(out_line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +278,17 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL; gloo lets several ranks rehearse on one GPU)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # Started plainly with --gpus N: this process becomes the launcher and nothing else.  It has touched neither torch nor the
+            # GPU (a process that has initialised the GPU must not start the ranks by exec), starts N ranks as a child through
+            # torch.distributed.run, relays what they print and leaves with the child's exit code.
+            sys.exit(launch_ranks(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher and the flag disagree "
+                         "(one rank per GPU; start it as `python bench.py --gpus N` or through torch.distributed.run with --nproc-per-node N)")
 
     import torch
     import torch.distributed as dist

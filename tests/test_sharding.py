@@ -143,7 +143,40 @@ def test_two_ranks_on_the_hip_path_code_what_one_rank_codes(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["slice_status_errors"] == 0
     assert line["config"]["batch_slices"] == 2048 and 0 < line["config"]["slices_per_gpu"] < 2048
     assert line["config"]["h264_bytes_all_gpus"] == single["config"]["h264_bytes_per_gpu"]        # the shards are the batch
+    # ... and the same started plainly, the way the driver starts its N = 1 line: `python bench.py --gpus 2` launches its own ranks
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", "strong"] + common,
+                           capture_output=True, text=True, env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
+                           timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    own = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    assert own["n_gpus"] == 2 and own["slice_status_errors"] == 0
+    assert own["config"]["h264_bytes_all_gpus"] == single["config"]["h264_bytes_per_gpu"]
     out = os.path.join(root, "gpurun_out")
     if os.path.isdir(out):                                   # kept for profiles/ (tools/collect_profiles.py)
         with open(os.path.join(out, "rehearsal_2ranks_w4.json"), "w") as f:
             f.write(json.dumps(line) + "\n")
+
+
+def test_bench_refuses_a_world_size_that_is_not_its_gpus_flag():
+    """`bench.py --gpus N` under a launcher that started another number of ranks must not print a line for the wrong N
+    (BASELINE.json's metric is quoted at 1/2/4/8 GPUs): it leaves non-zero before touching torch or the GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], capture_output=True, text=True,
+                       env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_with_gpus_flag_launches_that_many_ranks_itself():
+    """Started plainly with --gpus 2 and no launcher around it, bench.py starts two ranks (torch.distributed.run) and hands on their
+    exit code.  No GPU here: each rank leaves with the no-GPU message, and so does the launcher -- non-zero, nothing on stdout."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""                          # also on a GPU box this test stays a launch test
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--backend", "gloo"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-1500:]
