@@ -1,0 +1,90 @@
+// Micro-benchmark: GB/s of the ways a kernel of this library can read 2-byte records from HBM (event-timed, 640 MB = config 2's records).
+//   stream      16 B per lane, consecutive lanes consecutive addresses
+//   lane-chunk  a lane per 2 KiB chunk of its own, LINE bytes a trip with the next trip's loads in flight (k_k1p_local, k_k1p_replay)
+//   tile        64 chunks interleaved in 16-byte groups: a wave's load is one contiguous KiB (the layout of the one-lane-per-slice kernels)
+// hipcc --offload-arch=gfx950 -O3 -o read_patterns read_patterns.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+constexpr uint64_t kBytes = 640ull << 20;
+constexpr uint32_t kChunk = 2048;
+
+__global__ __launch_bounds__(256) void k_stream(const uint4 *in, uint32_t *out, uint64_t n16) {
+    uint32_t acc = 0;
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += gridDim.x * 256ull) { const uint4 v = in[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+template <int LINE, int WORK>
+__global__ __launch_bounds__(1024) void k_lane_chunk(const uint4 *in, uint32_t *out, uint64_t n_chunks) {
+    const uint64_t c = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint4 *q = in + c * (kChunk / 16);
+    constexpr int N = LINE / 16;
+    uint4 cur[N], nxt[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) cur[j] = q[j];
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t < kChunk / LINE; t++) {
+#pragma unroll
+        for (int j = 0; j < N; j++) nxt[j] = t + 1 < kChunk / LINE ? q[(t + 1) * N + j] : cur[j];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            uint32_t x = cur[j].x ^ cur[j].y ^ cur[j].z ^ cur[j].w;
+#pragma unroll
+            for (int k = 0; k < WORK; k++) x = x * 1664525u + 1013904223u;      // WORK dependent multiply-adds per 16 bytes (8 records)
+            acc += x;
+        }
+#pragma unroll
+        for (int j = 0; j < N; j++) cur[j] = nxt[j];
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+template <int WORK>
+__global__ __launch_bounds__(1024) void k_tile(const uint4 *in, uint32_t *out, uint64_t n_chunks) {
+    const uint64_t c = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint4 *q = in + (c >> 6) * 64 * (kChunk / 16) + (c & 63);       // group g of the tile's lane l at (64 g + l) * 16 bytes
+    uint4 cur = q[0];
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t < kChunk / 16; t++) {
+        const uint4 nxt = t + 1 < kChunk / 16 ? q[(t + 1) * 64] : cur;
+        uint32_t x = cur.x ^ cur.y ^ cur.z ^ cur.w;
+#pragma unroll
+        for (int k = 0; k < WORK; k++) x = x * 1664525u + 1013904223u;
+        acc += x;
+        cur = nxt;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <class F>
+static int timeit(const char *name, F &&launch) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 5; i++) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-64s %7.3f ms  %7.1f GB/s\n", name, ms / 5, kBytes / (ms / 5 * 1e-3) / 1e9);
+    return 0;
+}
+
+int main() {
+    uint4 *buf; uint32_t *out;
+    CK(hipMalloc(&buf, kBytes + 4096)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(buf, 1, kBytes + 4096));
+    const uint64_t nch = kBytes / kChunk;
+    timeit("stream, 16 B a lane", [&] { hipLaunchKernelGGL(k_stream, dim3(256 * 16), dim3(256), 0, 0, buf, out, kBytes / 16); });
+#define LC(LINE, WORK, BLK) timeit("lane-chunk, " #LINE " B a trip, work " #WORK ", workgroups of " #BLK, [&] { hipLaunchKernelGGL((k_lane_chunk<LINE, WORK>), dim3((nch + BLK - 1) / BLK), dim3(BLK), 0, 0, buf, out, nch); })
+    LC(64, 0, 256); LC(64, 0, 512); LC(64, 0, 1024); LC(128, 0, 256); LC(32, 0, 256); LC(16, 0, 256);
+    LC(64, 8, 256); LC(64, 32, 256); LC(64, 64, 256); LC(64, 64, 512); LC(128, 64, 256);
+#define TL(WORK, BLK) timeit("tile, 16 B a lane a trip, work " #WORK ", workgroups of " #BLK, [&] { hipLaunchKernelGGL((k_tile<WORK>), dim3((nch + BLK - 1) / BLK), dim3(BLK), 0, 0, buf, out, nch); })
+    TL(0, 256); TL(8, 256); TL(32, 256); TL(64, 256); TL(64, 512);
+    CK(hipFree(buf)); CK(hipFree(out));
+    return 0;
+}
