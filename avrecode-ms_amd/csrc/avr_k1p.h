@@ -222,8 +222,8 @@ AVR_HD void for_codes_all(const uint8_t *res, uint32_t from, uint32_t to, G &&g,
         const U4 *p = reinterpret_cast<const U4 *>(res + base);
         U4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
         for (; base + 64 <= to; base += 64) {
-            U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-            if (base + 128 <= to) { const U4 *q = reinterpret_cast<const U4 *>(res + base + 64); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+            const U4 *q = reinterpret_cast<const U4 *>(res + (base + 128 <= to ? base + 64 : base));   // unconditional: see c_stretch_in
+            const U4 n0 = q[0], n1 = q[1], n2 = q[2], n3 = q[3];
             group16(v0); group16(v1); group16(v2); group16(v3);
             v0 = n0; v1 = n1; v2 = n2; v3 = n3;
         }
@@ -437,7 +437,9 @@ AVR_HD void c_stretch_in(const Src &src, const Stretch &st, const Entry &en, uin
         if (base + 64 <= to) { v0 = src.load16(base); v1 = src.load16(base + 16); v2 = src.load16(base + 32); v3 = src.load16(base + 48); }
         for (; base + 64 <= to; base += 64) {              // a whole cache line per lane per trip, the next one in flight
             const uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-            if (base + 128 <= to) { v0 = src.load16(base + 64); v1 = src.load16(base + 80); v2 = src.load16(base + 96); v3 = src.load16(base + 112); }
+            // the next line unconditionally (past the last whole line: this one again, a hit) -- a load inside a branch is waited for at the branch's end
+            const uint32_t nb = base + 128 <= to ? base + 64 : base;
+            v0 = src.load16(nb); v1 = src.load16(nb + 16); v2 = src.load16(nb + 32); v3 = src.load16(nb + 48);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 4
 #endif

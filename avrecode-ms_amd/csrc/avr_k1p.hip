@@ -189,6 +189,29 @@ __global__ __launch_bounds__(256) void k_k1p_tn(uint8_t *tn) {
     tn[i] = uint8_t(st);
 }
 
+// A lane's walk over the 16-byte record groups [i0, i1) of its chunk (8 records a group; a slice's records are padded with no-ops to
+// a whole group): a cache line of 64 bytes a trip, the next trip's line in flight meanwhile.  The loads of the next line are
+// UNCONDITIONAL -- past the chunk's last whole line the address is clamped to that line (a hit) instead of the load being skipped: hipcc
+// puts a load inside a branch behind an exec mask and waits for it (s_waitcnt vmcnt) before the branch's end, which turned "the next
+// line in flight" into "every trip waits out a memory latency" in rounds 1-3 (tools/ubench/read_patterns: 1.4 against 4.3 TB/s for
+// this very pattern; more than one line ahead is slower again).
+template <class F>
+__device__ __forceinline__ void for_record_groups(const uint16_t *r, uint32_t i0, uint32_t i1, F &&f) {
+    uint32_t i = i0;
+    if (i + 32 <= i1) {
+        const uint32_t last = i0 + ((i1 - i0) / 32u - 1u) * 32u;                 // where the chunk's last whole line starts
+        const U4 *q = reinterpret_cast<const U4 *>(r + i);
+        U4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+        for (; i + 32 <= i1; i += 32) {
+            const U4 *qn = reinterpret_cast<const U4 *>(r + (i + 32 <= last ? i + 32 : last));
+            const U4 n0 = qn[0], n1 = qn[1], n2 = qn[2], n3 = qn[3];
+            f(v0); f(v1); f(v2); f(v3);
+            v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+        }
+    }
+    for (; i < i1; i += 8) f(*reinterpret_cast<const U4 *>(r + i));
+}
+
 // One lane per chunk: counting sort of the chunk's context bins by (dense) context, in LDS, serially.
 //   pass 1  count the bins of every context                    cnt[k][lane]++           (16-bit, lane-private)
 //   scan    exclusive prefix over the contexts                 cnt[k][lane] = first position of context k
@@ -257,18 +280,7 @@ __global__ __launch_bounds__(512) void k_k1p_local(Plan p, uint32_t total_chunks
     uint8_t *cnt_b = reinterpret_cast<uint8_t *>(my_cnt), *bits_b = reinterpret_cast<uint8_t *>(my_bits);
     // Visit the chunk's 16-byte groups (8 records; a slice's records are padded with no-ops to a whole group), a
     // cache line of records per trip with the next one in flight (see for_codes_all).
-    auto for_groups = [&](auto &&f) {
-        uint32_t i = i0;
-        U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
-        if (i + 32 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i); v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
-        for (; i + 32 <= i1; i += 32) {
-            U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-            if (i + 64 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i + 32); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
-            f(v0); f(v1); f(v2); f(v3);
-            v0 = n0; v1 = n1; v2 = n2; v3 = n3;
-        }
-        for (; i < i1; i += 8) f(*reinterpret_cast<const U4 *>(r + i));
-    };
+    auto for_groups = [&](auto &&f) { for_record_groups(r, i0, i1, f); };
     uint32_t high = 0;                                           // OR of all records: bits 12..15 must stay clear
     for_groups([&](const U4 &v) {                                // pass 1
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -406,8 +418,9 @@ __global__ __launch_bounds__(640) void k_k1p_local3(Plan p, uint32_t total_chunk
     uint32_t *my_cnt = cnt + lane;                               // keys 3j .. 3j+2 at my_cnt[64 j]
     uint32_t *my_bits = bits + lane;                             // dword j at my_bits[64 j]
     uint8_t *cnt_b = reinterpret_cast<uint8_t *>(my_cnt), *bits_b = reinterpret_cast<uint8_t *>(my_bits);
-    auto for_groups = [&](auto &&f) {                            // as k_k1p_local
-        uint32_t i = i0;
+    auto for_groups = [&](auto &&f) {
+        if (!AVR_ABL(32u)) { for_record_groups(r, i0, i1, f); return; }
+        uint32_t i = i0;                                         // measurement (hook local_ablate = 32): rounds 1-3's loop, the next line's loads inside a branch
         U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
         if (i + 32 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i); v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
         for (; i + 32 <= i1; i += 32) {
@@ -1054,16 +1067,15 @@ __global__ __launch_bounds__(256) void k_k1p_replay(Plan p, uint32_t total_chunk
     uint32_t i = i0;
     if (i0 < n) {
         U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+        const uint32_t last = i + 32 <= i1 ? i0 + ((i1 - i0) / 32u - 1u) * 32u : i0;      // where the chunk's last whole line starts
         if (i + 32 <= i1) {
             const U4 *q = reinterpret_cast<const U4 *>(r + i);
             v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3];
         }
         for (; i + 32 <= i1; i += 32) {                          // a cache line of records per trip, the next one in flight
-            U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-            if (i + 64 <= i1) {
-                const U4 *q = reinterpret_cast<const U4 *>(r + i + 32);
-                n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3];
-            }
+            // (loaded unconditionally, the address clamped to the chunk's last whole line: see for_record_groups)
+            const U4 *qn = reinterpret_cast<const U4 *>(r + (i + 32 <= last ? i + 32 : last));
+            const U4 n0 = qn[0], n1 = qn[1], n2 = qn[2], n3 = qn[3];
             U4 a, b;
             uint4 e[8];
             eight(v0, a.x, a.y, e); b1.group(i, e);
@@ -1154,8 +1166,8 @@ __global__ __launch_bounds__(256) void k_k1p_b1(Plan p, uint32_t total_chunks, c
         U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
         if (i + 64 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i); v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
         for (; i + 64 <= i1; i += 64) {
-            U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-            if (i + 128 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i + 64); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+            const U4 *qn = reinterpret_cast<const U4 *>(r + (i + 128 <= i1 ? i + 64 : i));     // unconditional: see for_record_groups
+            const U4 n0 = qn[0], n1 = qn[1], n2 = qn[2], n3 = qn[3];
             sixteen(i, v0); sixteen(i + 16, v1); sixteen(i + 32, v2); sixteen(i + 48, v3);
             v0 = n0; v1 = n1; v2 = n2; v3 = n3;
         }

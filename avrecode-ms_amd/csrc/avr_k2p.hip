@@ -464,8 +464,10 @@ __global__ __launch_bounds__(256) void k_k2p_code(K2Plan p, uint32_t n_slices, u
     U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
     if (i + 32 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i); v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
     for (; i + 32 <= i1; i += 32) {
-        U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-        if (i + 64 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i + 32); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
+        // the next line unconditionally (at the chunk's last whole line: that line again, a hit): a load inside a branch is waited for
+        // at the branch's end, which made every trip wait out a memory latency (tools/ubench/read_patterns)
+        const U4 *qn = reinterpret_cast<const U4 *>(r + (i + 64 <= i1 ? i + 32 : i));
+        const U4 n0 = qn[0], n1 = qn[1], n2 = qn[2], n3 = qn[3];
         eight<true>(v0, inv, low, range, add); eight<true>(v1, inv, low, range, add);
         eight<true>(v2, inv, low, range, add); eight<true>(v3, inv, low, range, add);
         v0 = n0; v1 = n1; v2 = n2; v3 = n3;

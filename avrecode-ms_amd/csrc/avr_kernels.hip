@@ -400,15 +400,19 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
     const ChunkSource<TILED> src(recs, off, in_range ? g : 0, slice);
     const uint32_t n_chunks = (nb + 7) >> 3;
     const uint4 nop4 = make_uint4(AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2, AVR_NOP_CABAC2);
-    uint4 cur = n_chunks > 0 ? src.load(0) : nop4;
-    uint4 nx1 = n_chunks > 1 ? src.load(1) : nop4;
+    // every load is unconditional (the index clamped to the slice's last chunk; what a clamped load returns is never coded): a load
+    // inside a branch is waited for before the branch ends -- the "two chunks ahead" of rounds 1-3 waited out a memory latency per
+    // eight bins (the same in k_range_encode since round 2; tools/ubench/read_patterns)
+    const uint32_t last_chunk = n_chunks ? n_chunks - 1 : 0;
+    uint4 cur = nop4, nx1 = nop4;
+    if (n_chunks) { cur = src.load(0); nx1 = src.load(min(1u, last_chunk)); }
     // put_terminate(1) (cabac_code.h:63-65) ends the slice: in a well-formed stream it is the last record,
     // and what follows it in its 16-byte chunk is padding that changes nothing, so the bins are not
     // tested one by one for it -- its position is only remembered (a bin after it flags the slice).
     uint32_t term_at = 0xffffffffu;                              // record index of the first put_terminate(1)
     constexpr uint32_t kTerm1 = (AVR_SEL_TERMINATE << 1) | 1;
     for (uint32_t c = 0; c < n_chunks && term_at == 0xffffffffu; c++) {
-        const uint4 nx2 = (c + 2 < n_chunks) ? src.load(c + 2) : nop4;
+        const uint4 nx2 = src.load(min(c + 2, last_chunk));
         const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
         uint32_t offs[8];                                        // where the eight bins' states live: independent of the states, read ahead
 #pragma unroll

@@ -165,6 +165,28 @@ def test_chunked_full_size_config2_sampled(avr, oracle):
     assert w.results()[0] == again == got
 
 
+def test_chunked_full_size_config2_every_slice(avr, oracle):
+    """The headline path (BASELINE.json configs[1] through encode_chunked(), i.e. K1p) with EVERY one of its 512 slices against the
+    oracle -- cabac_code.h:33-67 on arithmetic_code.h, threaded over the host's cores -- through a checksum of checksums, and the
+    final context states of every slice beside the bytes (the twin of test_range_chunked_full_size's check of the compress direction)."""
+    import hashlib
+    n_slices = 512
+    w = avr.DeviceWorkload.synth(2, n_slices, avr.KIND_CABAC, 0, 1000)
+    w.encode_chunked()
+    got, status = w.results()
+    assert not any(status)
+    cfg, nbh, off, recs, states = host_synth(avr, 2, n_slices, avr.KIND_CABAC, 1000)
+    assert np.array_equal(nbh, w.n_bins.cpu().numpy())
+    parts = [recs[int(off[i]):int(off[i]) + int(nbh[i])] for i in range(n_slices)]
+    roff = np.zeros(n_slices + 1, np.uint64)
+    roff[1:] = np.cumsum(nbh.astype(np.uint64))
+    want, st = oracle.encode_batch(avr.KIND_CABAC, np.concatenate(parts), roff, states, cfg.n_states, threads=16)
+    assert not st.any()
+    dig = lambda chunks: hashlib.sha256(b"".join(hashlib.sha256(c).digest() for c in chunks)).hexdigest()
+    assert [len(x) for x in got] == [len(x) for x in want]
+    assert dig(got) == dig(want)
+
+
 def test_batch_api_takes_the_chunked_path_for_long_slices(avr, oracle, hooks):
     rng = np.random.default_rng(77)
     slices = [oracle_lib.random_cabac_stream(rng, int(rng.integers(15000, 40000)), 200) for _ in range(12)]
@@ -337,7 +359,9 @@ def test_chunked_full_size_configs_3_and_4_sampled(avr, oracle, workload, n_slic
     again, _ = w.results()
     assert again == got
     nb = w.n_bins.cpu().numpy()
-    sample = sorted(set(np.random.default_rng(workload).integers(0, n_slices, 24).tolist() + [0, n_slices - 1, int(nb.argmax()), int(nb.argmin())]))
+    # every slice of the first and of the last tile of 64 (where a batch's grid begins and ends), 24 random ones, the longest and the shortest
+    sample = sorted(set(np.random.default_rng(workload).integers(0, n_slices, 24).tolist() + list(range(64)) + list(range(n_slices - 64, n_slices))
+                        + [int(nb.argmax()), int(nb.argmin())]))
     for s in sample:
         cfg, nbh, off, recs, states = host_synth(avr, workload, 1, 0, 1000, first=s)
         assert int(nbh[0]) == int(nb[s])

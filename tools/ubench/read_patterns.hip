@@ -25,6 +25,7 @@ __global__ __launch_bounds__(1024) void k_lane_chunk(const uint4 *in, uint32_t *
 #pragma unroll
     for (int j = 0; j < N; j++) cur[j] = q[j];
     uint32_t acc = 0;
+#pragma unroll 1
     for (uint32_t t = 0; t < kChunk / LINE; t++) {
 #pragma unroll
         for (int j = 0; j < N; j++) nxt[j] = t + 1 < kChunk / LINE ? q[(t + 1) * N + j] : cur[j];
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(1024) void k_lane_chunk(const uint4 *in, uint32_t *
         for (int j = 0; j < N; j++) {
             uint32_t x = cur[j].x ^ cur[j].y ^ cur[j].z ^ cur[j].w;
 #pragma unroll
-            for (int k = 0; k < WORK; k++) x = x * 1664525u + 1013904223u;      // WORK dependent multiply-adds per 16 bytes (8 records)
+            for (int k = 0; k < WORK; k++) x = __builtin_amdgcn_perm(x, acc, x) + k;      // WORK dependent instructions per 16 bytes (8 records)
             acc += x;
         }
 #pragma unroll
@@ -42,20 +43,58 @@ __global__ __launch_bounds__(1024) void k_lane_chunk(const uint4 *in, uint32_t *
 }
 template <int WORK>
 __global__ __launch_bounds__(1024) void k_tile(const uint4 *in, uint32_t *out, uint64_t n_chunks) {
+    extern __shared__ uint32_t dyn[];
     const uint64_t c = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
     if (c >= n_chunks) return;
     const uint4 *q = in + (c >> 6) * 64 * (kChunk / 16) + (c & 63);       // group g of the tile's lane l at (64 g + l) * 16 bytes
     uint4 cur = q[0];
     uint32_t acc = 0;
+#pragma unroll 1
     for (uint32_t t = 0; t < kChunk / 16; t++) {
         const uint4 nxt = t + 1 < kChunk / 16 ? q[(t + 1) * 64] : cur;
         uint32_t x = cur.x ^ cur.y ^ cur.z ^ cur.w;
 #pragma unroll
-        for (int k = 0; k < WORK; k++) x = x * 1664525u + 1013904223u;
+        for (int k = 0; k < WORK; k++) x = __builtin_amdgcn_perm(x, acc, x) + k;
         acc += x;
         cur = nxt;
     }
     if (acc == 0x12345678u) out[0] = acc;
+}
+
+// D cache lines (64 B each) of the lane's chunk in flight, rolled loop: the ring of registers is rotated by hand
+template <int D>
+__global__ __launch_bounds__(1024) void k_lane_deep(const uint4 *in, uint32_t *out, uint64_t n_chunks) {
+    extern __shared__ uint32_t dyn[];
+    const uint64_t c = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint4 *q = in + c * (kChunk / 16);
+    uint4 ring[D][4];
+#pragma unroll
+    for (int d = 0; d < D; d++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) ring[d][j] = q[d * 4 + j];
+    uint32_t acc = 0;
+    constexpr uint32_t trips = kChunk / 64;
+#pragma unroll 1
+    for (uint32_t t = 0; t < trips; t += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            uint4 cur[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) cur[j] = ring[d][j];
+            const uint32_t nt = t + d + D < trips ? t + d + D : trips - 1;          // never a load inside a branch: the index is clamped instead
+#pragma unroll
+            for (int j = 0; j < 4; j++) ring[d][j] = q[nt * 4 + j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t x = cur[j].x ^ cur[j].y ^ cur[j].z ^ cur[j].w;
+#pragma unroll
+                for (int k = 0; k < 8; k++) x = __builtin_amdgcn_perm(x, acc, x) + k;
+                acc += x;
+            }
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc + dyn[0];
 }
 
 template <class F>
@@ -81,10 +120,21 @@ int main() {
     const uint64_t nch = kBytes / kChunk;
     timeit("stream, 16 B a lane", [&] { hipLaunchKernelGGL(k_stream, dim3(256 * 16), dim3(256), 0, 0, buf, out, kBytes / 16); });
 #define LC(LINE, WORK, BLK) timeit("lane-chunk, " #LINE " B a trip, work " #WORK ", workgroups of " #BLK, [&] { hipLaunchKernelGGL((k_lane_chunk<LINE, WORK>), dim3((nch + BLK - 1) / BLK), dim3(BLK), 0, 0, buf, out, nch); })
-    LC(64, 0, 256); LC(64, 0, 512); LC(64, 0, 1024); LC(128, 0, 256); LC(32, 0, 256); LC(16, 0, 256);
-    LC(64, 8, 256); LC(64, 32, 256); LC(64, 64, 256); LC(64, 64, 512); LC(128, 64, 256);
 #define TL(WORK, BLK) timeit("tile, 16 B a lane a trip, work " #WORK ", workgroups of " #BLK, [&] { hipLaunchKernelGGL((k_tile<WORK>), dim3((nch + BLK - 1) / BLK), dim3(BLK), 0, 0, buf, out, nch); })
-    TL(0, 256); TL(8, 256); TL(32, 256); TL(64, 256); TL(64, 512);
+    LC(64, 0, 256); LC(64, 8, 256); LC(64, 64, 256); LC(128, 8, 256); LC(32, 8, 256); LC(16, 8, 256);
+    TL(0, 256); TL(8, 256); TL(64, 256);
+    // by waves a CU (dynamic LDS holds the occupancy down) and by cache lines in flight per lane
+    for (uint32_t waves : {8u, 10u, 12u, 16u, 32u}) {
+        const uint32_t lds = (160u * 1024 / waves / 1024) * 1024 * 4 - 1024;      // per workgroup of 4 waves: waves / 4 workgroups fit
+        char name[128];
+#define DEEP(D) { CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lane_deep<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        snprintf(name, sizeof name, "lane-chunk, %d lines in flight, %u waves a CU", D, waves); \
+        if (timeit(name, [&] { hipLaunchKernelGGL((k_lane_deep<D>), dim3((nch + 255) / 256), dim3(256), lds, 0, buf, out, nch); })) return 1; }
+        DEEP(1) DEEP(2) DEEP(4) DEEP(8)
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        snprintf(name, sizeof name, "tile 16 B a trip, %u waves a CU", waves);
+        if (timeit(name, [&] { hipLaunchKernelGGL((k_tile<8>), dim3((nch + 255) / 256), dim3(256), lds, 0, buf, out, nch); })) return 1;
+    }
     CK(hipFree(buf)); CK(hipFree(out));
     return 0;
 }
