@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_k1p_tn(uint8_t *tn) {
 // UNCONDITIONAL -- past the chunk's last whole line the address is clamped to that line (a hit) instead of the load being skipped: hipcc
 // puts a load inside a branch behind an exec mask and waits for it (s_waitcnt vmcnt) before the branch's end, which turned "the next
 // line in flight" into "every trip waits out a memory latency" in rounds 1-3 (tools/ubench/read_patterns: 1.4 against 4.3 TB/s for
-// this very pattern; more than one line ahead is slower again).
+// this very pattern at ten waves a CU; more than one line ahead is slower again: 2.4 TB/s with two, 1.0 with four).
 template <class F>
 __device__ __forceinline__ void for_record_groups(const uint16_t *r, uint32_t i0, uint32_t i1, F &&f) {
     uint32_t i = i0;
@@ -353,181 +353,6 @@ __global__ __launch_bounds__(512) void k_k1p_local(Plan p, uint32_t total_chunks
             dst[f] = uint16_t(cnt[64 * (k >> 1) + ch] >> (16 * (k & 1u)));
             ch += dch; k += dk;
             if (k >= nk) { k -= nk; ch++; }
-        }
-    }
-}
-
-// The same sort with THREE counters to a dword (round 4).  What bounds k_k1p_local is not its arithmetic but how many of its waves a CU
-// holds: a wave waits on LDS round trips most of the time (48 % of its cycles on config 2) and its footprint -- 33 rows of bits and a row
-// per two contexts -- lets eight waves share a CU's 160 KiB when a batch has 86 contexts: two a SIMD, and config 2's 4 736 waves take three
-// rounds of 2 048, the last one a third full.  Positions run to 1 024, i.e. 11 bits: fields at bits 0 and 11 (11 bits each) and 22 (10
-// bits, whose carry falls off the top of the dword: nothing it can spill into) make a row per THREE contexts; with the selector table cut
-// to the 1 028 selectors that can mean something (index min(selector, 1027)) ten waves fit -- two rounds of 2 560 instead of three.
-//   * A field-2 counter that reaches 1 024 reads 0.  For an END position (all the chunk's sorted bins lie at or before this context) that
-//     is repaired on the way out: ends never decrease along the contexts, so a 0 behind the chunk's first non-empty context means 1 024.
-//     For a COUNT (all 1 024 bins of the chunk in one field-2 context) it would misplace the chunk: the counts then do not add up to the
-//     records visited, and the slice is handed to the serial kernel (AVR_SLICE_RETRY_SERIAL).
-//   * Bypass bins, padding, contexts the census missed and selectors that mean nothing share ONE spare counter (a dword of its own, set to
-//     1 024 before the placement so that their bits land in the spare row); which of them occurred comes from the OR of the table
-//     entries (bits 6, 7: no field uses them as a shift).
-constexpr uint32_t kSelEntries = 1028;                            // selectors 0 .. 1026 and "anything else"
-constexpr uint32_t kLocalMissed = 0x40u, kLocalInvalid = 0x80u;
-#ifdef AVR_TEST_HOOKS
-#define AVR_ABL(bit) (abl & (bit))          // measurement only (hook local_ablate): parts of the kernel left out, results wrong
-#else
-#define AVR_ABL(bit) false
-#endif
-__global__ __launch_bounds__(640) void k_k1p_local3(Plan p, uint32_t total_chunks, int32_t *status, uint32_t *lbits,
-                                                    uint16_t *lend, uint32_t *n_retry, uint32_t abl) {
-    (void)abl;
-    extern __shared__ uint32_t local_lds[];                      // per wave: bits[33][64], then cnt[rows_ctx + 1][64]
-    __shared__ uint16_t sel_tab[kSelEntries];
-    const uint32_t nk = p.n_states, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t rows_ctx = (nk + 3) / 3;                      // keys 0 .. nk (the contexts, then the terminate bins), three to a row
-    const uint32_t cnt_rows = rows_ctx + 1;                      // + the spare counter
-    const uint32_t wave_dwords = (33 + cnt_rows) * 64;
-    uint32_t *bits = local_lds + wv * wave_dwords;
-    uint32_t *cnt = bits + 33 * 64;
-    for (uint32_t sel = threadIdx.x; sel < kSelEntries; sel += blockDim.x) {
-        uint32_t k, flag = 0;
-        if (sel < 1024u) {
-            const uint32_t d = p.table[sel];
-            k = d < nk ? d : kNone;
-            if (k == kNone) flag = sel < p.ns_full ? kLocalMissed : kLocalInvalid;
-        } else if (sel == AVR_SEL_TERMINATE) k = nk;
-        else { k = kNone; if (!(sel == AVR_SEL_BYPASS || sel == (AVR_NOP_CABAC >> 1))) flag = kLocalInvalid; }
-        sel_tab[sel] = uint16_t(k == kNone ? (rows_ctx << 8) | flag : ((k / 3u) << 8) | (k % 3u) * 11u);
-    }
-    for (uint32_t i = lane; i < wave_dwords; i += 64) bits[i] = 0;
-    __syncthreads();
-    const uint32_t gc0 = (blockIdx.x * (blockDim.x >> 6) + wv) * 64, gc = gc0 + lane;
-    uint32_t i0 = 0, i1 = 0, n = 0, s = 0;
-    bool mine = false;                                           // the lane has a chunk of a live slice
-    const uint16_t *r = p.recs;
-    if (gc < total_chunks) {
-        s = p.chunk_slice[gc];
-        if (status[s] == AVR_SLICE_OK) {
-            mine = true;
-            n = p.n_bins[s];
-            i0 = (gc - p.chunk_base[s]) * kChunk;
-            i1 = i0 + kChunk < n ? i0 + kChunk : n;
-            if (i0 > i1) i0 = i1;
-            r = p.recs + p.rec_off[s];
-        }
-    }
-    uint32_t *my_cnt = cnt + lane;                               // keys 3j .. 3j+2 at my_cnt[64 j]
-    uint32_t *my_bits = bits + lane;                             // dword j at my_bits[64 j]
-    uint8_t *cnt_b = reinterpret_cast<uint8_t *>(my_cnt), *bits_b = reinterpret_cast<uint8_t *>(my_bits);
-    auto for_groups = [&](auto &&f) {
-        if (!AVR_ABL(32u)) { for_record_groups(r, i0, i1, f); return; }
-        uint32_t i = i0;                                         // measurement (hook local_ablate = 32): rounds 1-3's loop, the next line's loads inside a branch
-        U4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
-        if (i + 32 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i); v0 = q[0]; v1 = q[1]; v2 = q[2]; v3 = q[3]; }
-        for (; i + 32 <= i1; i += 32) {
-            U4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-            if (i + 64 <= i1) { const U4 *q = reinterpret_cast<const U4 *>(r + i + 32); n0 = q[0]; n1 = q[1]; n2 = q[2]; n3 = q[3]; }
-            f(v0); f(v1); f(v2); f(v3);
-            v0 = n0; v1 = n1; v2 = n2; v3 = n3;
-        }
-        for (; i < i1; i += 8) f(*reinterpret_cast<const U4 *>(r + i));
-    };
-    auto entry = [&](uint32_t rec) {                             // rec: the record in the low 16 bits (anything above)
-        const uint32_t sel = (rec >> 1) & 0x7ffu;
-        if (AVR_ABL(16u)) return ((sel & 15u) << 8) | (sel & 1u) * 11u;
-        return uint32_t(sel_tab[sel < kSelEntries - 1 ? sel : kSelEntries - 1]);
-    };
-    uint32_t high = 0, flags = 0;                                // OR of all records (bits 12..15 must stay clear) and of all table entries
-    for_groups([&](const U4 &v) {                                // pass 1
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        high |= (w[0] | w[1]) | (w[2] | w[3]);
-        uint32_t e[8];
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++) e[j] = entry(w[j >> 1] >> ((j & 1) * 16));
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            flags |= e[j];
-            if (!AVR_ABL(2u))
-            __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(cnt_b + (e[j] & 0xff00u)), 1u << (e[j] & 31u), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    });
-    const uint32_t visited = (i1 - i0 + 7u) & ~7u;               // records of the chunk, its last group's padding included
-    uint32_t term_at = 0, n_term = 0, run = 0, k_first = kNone;
-    {
-        // exclusive prefix over the keys 0 .. nk; the counts must add up to the records visited (see above: a wrapped field-2 count)
-        uint32_t total = my_cnt[64 * rows_ctx];
-        for (uint32_t j = 0; j < rows_ctx; j++) {
-            const uint32_t c = my_cnt[64 * j], c0 = c & 2047u, c1 = (c >> 11) & 2047u, c2 = c >> 22;
-            const uint32_t s0 = run, s1 = run + c0, s2 = run + c0 + c1;
-            if (3 * j == nk) { term_at = s0; n_term = c0; }
-            if (3 * j + 1 == nk) { term_at = s1; n_term = c1; }
-            if (3 * j + 2 == nk) { term_at = s2; n_term = c2; }
-            if (k_first == kNone && (c0 | c1 | c2)) k_first = 3 * j + (c0 ? 0u : c1 ? 1u : 2u);
-            my_cnt[64 * j] = s0 | s1 << 11 | s2 << 22;           // (a start of 1 024 in field 2 reads 0: such a context has no bins)
-            run += c0 + c1 + c2;
-            total += c0 + c1 + c2;
-        }
-        my_cnt[64 * rows_ctx] = 1024u;                           // the spare counter: from position 1 024 on, i.e. into the spare row of `bits`
-        if (mine && total != visited && !AVR_ABL(0xffu)) status[s] = AVR_SLICE_RETRY_SERIAL;
-    }
-    if (!AVR_ABL(1u))
-    for_groups([&](const U4 &v) {                                // pass 2
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t e[8], pos[8];
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++) e[j] = entry(w[j >> 1] >> ((j & 1) * 16));
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++)
-            pos[j] = AVR_ABL(4u) ? 0u : __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(cnt_b + (e[j] & 0xff00u)), 1u << (e[j] & 31u), __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            const uint32_t at = (pos[j] >> (e[j] & 31u)) & 2047u;            // < 1024: a sorted bin's place; the spare counter counts from 1024
-            const uint32_t row = at >> 5 < 32u ? at >> 5 : 32u;
-            const uint32_t bin = (w[j >> 1] >> ((j & 1) * 16)) & 1u;
-            if (!AVR_ABL(8u))
-            __hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(bits_b + row * 256u), bin << (at & 31u), __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    });
-    if (mine) {
-        uint32_t ones = 0;                                       // put_terminate(1) among the chunk's terminate bins
-        for (uint32_t pos = term_at; pos < term_at + n_term;) {
-            const uint32_t lo = pos & 31u, take = 32u - lo < term_at + n_term - pos ? 32u - lo : term_at + n_term - pos;
-            const uint32_t mask = (take == 32u ? 0xffffffffu : (1u << take) - 1u) << lo;
-            ones += __popc(my_bits[64 * (pos >> 5)] & mask);
-            pos += take;
-        }
-        constexpr uint32_t kTerm1 = (AVR_SEL_TERMINATE << 1) | 1;
-        const bool bad_term = ones > 1u || (ones == 1u && !(i1 == n && r[n - 1] == kTerm1));   // one 1: it is the last bin iff the last bin is one
-        if (AVR_ABL(0xffu)) {}
-        else if ((flags & kLocalInvalid) || (high & 0xf000f000u) || bad_term) status[s] = AVR_SLICE_BAD_RECORD;
-        else if ((flags & kLocalMissed) && atomicCAS(&status[s], AVR_SLICE_OK, AVR_SLICE_RETRY_CENSUS) == AVR_SLICE_OK) atomicAdd(n_retry, 1u);
-    }
-    // what the repair of a wrapped end needs, where the lane that writes this lane's ends will find it: the spare counter's dword
-    my_cnt[64 * rows_ctx] = (run == 1024u ? 0x80000000u : 0u) | (k_first & 0xffffu);
-    // out, transposed: flat element f of the wave's 64 rows <-> (chunk f / row, column f % row)
-    {
-        uint32_t *dst = lbits + size_t(gc0) * 32;
-        const uint32_t lim = gc0 < total_chunks ? (total_chunks - gc0 < 64 ? total_chunks - gc0 : 64) * 32 : 0;
-        for (uint32_t f = lane; f < lim; f += 64) dst[f] = bits[64 * (f & 31u) + (f >> 5)];
-    }
-    if (nk) {
-        uint16_t *dst = lend + size_t(gc0) * nk;
-        const uint32_t lim = gc0 < total_chunks ? (total_chunks - gc0 < 64 ? total_chunks - gc0 : 64) * nk : 0;
-        uint32_t ch = lane / nk, k = lane - ch * nk;
-        const uint32_t dch = 64 / nk, dk = 64 - dch * nk;
-        uint32_t row = k / 3u, fld = k - 3u * row;               // kept in step with k (no division in the loop)
-        for (uint32_t f = lane; f < lim; f += 64) {
-            uint32_t v = (cnt[64 * row + ch] >> (11u * fld)) & 2047u;
-            if (fld == 2u && v == 0u) {                          // 0 or a wrapped 1 024
-                const uint32_t info = cnt[64 * rows_ctx + ch];
-                if ((info >> 31) && k >= (info & 0xffffu)) v = 1024u;
-            }
-            dst[f] = uint16_t(v);
-            ch += dch; k += dk;
-            if (k >= nk) { k -= nk; ch++; }
-            row = k / 3u; fld = k - 3u * row;
         }
     }
 }
@@ -1579,47 +1404,32 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
         // the waves of a workgroup share the renumbering table; each has its own counters and bit strings
         // as many waves to a CU as its LDS takes (the kernel waits on LDS round trips: two waves a SIMD against one and a half is
         // what there is to win), as workgroups of w waves: the w with the most waves resident, the smaller workgroup on a tie
-        const uint32_t kLdsPerCu = 160 * 1024;
-        // two counters to a dword (k_k1p_local) or three (k_k1p_local3): whichever puts more waves on a CU; the cheaper step on a tie
-        const uint32_t per_wave2 = (33 + (n_states + 5) / 2) * 64 * 4, per_wave3 = (33 + (n_states + 3) / 3 + 1) * 64 * 4;
+        const uint32_t per_wave = (33 + (n_states + 5) / 2) * 64 * 4;
         const bool narrow = n_states <= 500;                     // (rows up to (n_states + 3) / 2 = 251: offsets below 2^16)
-        const uint32_t static2 = narrow ? 2048 * 2 : 2048 * 4, static3 = ((kSelEntries * 2 + 15) / 16) * 16;
-        auto fit = [&](uint32_t per_wave, uint32_t fixed, uint32_t max_waves, uint32_t *waves) {
-            uint32_t best = 0;
-            *waves = 1;
-            for (uint32_t w = 1; w <= max_waves; w++) {
-                const uint32_t need = w * per_wave + fixed;
-                if (need > kLdsPerCu) break;
-                const uint32_t resident = kLdsPerCu / need * w;
-                if (resident > best) { best = resident; *waves = w; }
-            }
-            return best;
-        };
-        uint32_t waves2 = 1, waves3 = 1;
-        const uint32_t res2 = fit(per_wave2, static2, 8, &waves2);
-        const uint32_t res3 = n_states + 3 <= 3 * 255 ? fit(per_wave3, static3, 10, &waves3) : 0;        // (row numbers in a byte)
-        bool three = res3 > res2;
-        if (const uint32_t v = test_hooks().local_fields) three = v == 3 && res3 > 0;
-        const uint32_t per_wave = three ? per_wave3 : per_wave2;
-        uint32_t waves = three ? waves3 : waves2;
-        const void *local = three ? reinterpret_cast<const void *>(k_k1p_local3)
-                                  : narrow ? reinterpret_cast<const void *>(k_k1p_local<uint16_t>) : reinterpret_cast<const void *>(k_k1p_local<uint32_t>);
-        if (const uint32_t v = test_hooks().local_waves) waves = v < (three ? 10u : 8u) ? v : (three ? 10u : 8u);
+        const uint32_t kLdsPerCu = 160 * 1024, kStatic = narrow ? 2048 * 2 : 2048 * 4;
+        auto local = narrow ? k_k1p_local<uint16_t> : k_k1p_local<uint32_t>;
+        uint32_t waves = 1, best = 0;
+        for (uint32_t w = 1; w <= 8; w++) {
+            const uint32_t need = w * per_wave + kStatic;
+            if (need > kLdsPerCu) break;
+            const uint32_t resident = kLdsPerCu / need * w;
+            if (resident > best) { best = resident; waves = w; }
+        }
+        if (const uint32_t v = test_hooks().local_waves) waves = v;
         uint32_t lds = waves * per_wave;
         if (lds > 60 * 1024) {
-            e = hipFuncSetAttribute(local, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(local), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
             if (e != hipSuccess && waves > 1) {                  // a runtime that grants a workgroup less than the CU has: the small workgroups
                 (void)hipGetLastError();
                 waves = per_wave * 2 <= 60 * 1024 ? 2 : 1;
                 lds = waves * per_wave;
-                e = lds > 60 * 1024 ? hipFuncSetAttribute(local, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) : hipSuccess;
+                e = lds > 60 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(local), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds))
+                                    : hipSuccess;
             }
             if (e != hipSuccess) return e;
         }
-        const dim3 lgrid((pl->total_chunks + 64 * waves - 1) / (64 * waves)), lblock(64 * waves);
-        if (three) hipLaunchKernelGGL(k_k1p_local3, lgrid, lblock, lds, s, p, pl->total_chunks, status, lbits, lend, n_retry, test_hooks().local_ablate);
-        else if (narrow) hipLaunchKernelGGL(k_k1p_local<uint16_t>, lgrid, lblock, lds, s, p, pl->total_chunks, status, lbits, lend, n_retry);
-        else hipLaunchKernelGGL(k_k1p_local<uint32_t>, lgrid, lblock, lds, s, p, pl->total_chunks, status, lbits, lend, n_retry);
+        hipLaunchKernelGGL(local, dim3((pl->total_chunks + 64 * waves - 1) / (64 * waves)), dim3(64 * waves), lds, s, p,
+                           pl->total_chunks, status, lbits, lend, n_retry);
         // How many slices k_k1p_local set aside for the second pass.  Read here, not at the end of the pass: the kernels that
         // follow are launched while the device is still busy with this one's successors only for a moment, where a wait
         // after the last kernel would leave the device idle until the caller's next launch.

@@ -97,6 +97,33 @@ __global__ __launch_bounds__(1024) void k_lane_deep(const uint4 *in, uint32_t *o
     if (acc == 0x12345678u) out[0] = acc + dyn[0];
 }
 
+// the tile pattern with D trips (16 B a lane each) in flight, 1 or 2 bytes a record: what a pass over wave-interleaved records costs at low occupancy
+template <int D>
+__global__ __launch_bounds__(1024) void k_tile_deep(const uint4 *in, uint32_t *out, uint64_t n_chunks, uint32_t chunk16) {
+    extern __shared__ uint32_t dyn[];
+    const uint64_t c = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint4 *q = in + (c >> 6) * 64 * chunk16 + (c & 63);
+    uint4 ring[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) ring[d] = q[d * 64];
+    uint32_t acc = 0;
+#pragma unroll 1
+    for (uint32_t t = 0; t < chunk16; t += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const uint4 cur = ring[d];
+            const uint32_t nt = t + d + D < chunk16 ? t + d + D : chunk16 - 1;
+            ring[d] = q[nt * 64];
+            uint32_t x = cur.x ^ cur.y ^ cur.z ^ cur.w;
+#pragma unroll
+            for (int k = 0; k < 8; k++) x = __builtin_amdgcn_perm(x, acc, x) + k;
+            acc += x;
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc + dyn[0];
+}
+
 template <class F>
 static int timeit(const char *name, F &&launch) {
     hipEvent_t e0, e1;
@@ -123,17 +150,14 @@ int main() {
 #define TL(WORK, BLK) timeit("tile, 16 B a lane a trip, work " #WORK ", workgroups of " #BLK, [&] { hipLaunchKernelGGL((k_tile<WORK>), dim3((nch + BLK - 1) / BLK), dim3(BLK), 0, 0, buf, out, nch); })
     LC(64, 0, 256); LC(64, 8, 256); LC(64, 64, 256); LC(128, 8, 256); LC(32, 8, 256); LC(16, 8, 256);
     TL(0, 256); TL(8, 256); TL(64, 256);
-    // by waves a CU (dynamic LDS holds the occupancy down) and by cache lines in flight per lane
-    for (uint32_t waves : {8u, 10u, 12u, 16u, 32u}) {
+    // by waves a CU (dynamic LDS holds the occupancy down): tiles with D trips in flight, 2 B records (128 trips a chunk) and 1 B records (64)
+    for (uint32_t waves : {8u, 10u, 12u, 20u}) {
         const uint32_t lds = (160u * 1024 / waves / 1024) * 1024 * 4 - 1024;      // per workgroup of 4 waves: waves / 4 workgroups fit
         char name[128];
-#define DEEP(D) { CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lane_deep<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        snprintf(name, sizeof name, "lane-chunk, %d lines in flight, %u waves a CU", D, waves); \
-        if (timeit(name, [&] { hipLaunchKernelGGL((k_lane_deep<D>), dim3((nch + 255) / 256), dim3(256), lds, 0, buf, out, nch); })) return 1; }
-        DEEP(1) DEEP(2) DEEP(4) DEEP(8)
-        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        snprintf(name, sizeof name, "tile 16 B a trip, %u waves a CU", waves);
-        if (timeit(name, [&] { hipLaunchKernelGGL((k_tile<8>), dim3((nch + 255) / 256), dim3(256), lds, 0, buf, out, nch); })) return 1;
+#define TDEEP(D, C16) { CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_deep<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        snprintf(name, sizeof name, "tile, %d trips in flight, %u B a chunk, %u waves a CU (ms for 310 M records)", D, C16 * 16, waves); \
+        if (timeit(name, [&] { hipLaunchKernelGGL((k_tile_deep<D>), dim3((nch + 255) / 256), dim3(256), lds, 0, buf, out, nch, C16); })) return 1; }
+        TDEEP(1, 128) TDEEP(2, 128) TDEEP(4, 128) TDEEP(8, 128) TDEEP(1, 64) TDEEP(2, 64) TDEEP(4, 64) TDEEP(8, 64)
     }
     CK(hipFree(buf)); CK(hipFree(out));
     return 0;
