@@ -30,8 +30,9 @@ LIB_PATH = os.path.join(_HERE, "libavrecode_hip.so")
 HOOKS_LIB_PATH = os.path.join(_HERE, "libavrecode_hip_hooks.so")   # -DAVR_TEST_HOOKS build, for tests/ only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "avrecode_ms_amd.h")
 
-KIND_CABAC, KIND_RANGE, KIND_CABAC_CODES = 0, 1, 2
+KIND_CABAC, KIND_RANGE, KIND_CABAC_CODES, KIND_CABAC8 = 0, 1, 2, 3
 SEL_BYPASS, SEL_TERMINATE = 1024, 1025
+SEL8_BYPASS, SEL8_TERMINATE, MAX_STATES8 = 126, 127, 126      # one-byte records (KIND_CABAC8)
 SLICE_OK, SLICE_ZERO_PROB, SLICE_OVERFLOW, SLICE_BAD_RECORD = 0, 1, 2, 3
 NOP_CABAC, NOP_RANGE = 1026 << 1, 0
 CHUNK_BINS, SORT_BLOCK_BINS = 1024, 4096
@@ -132,6 +133,7 @@ SIGNATURES = {
     "avr_batch_add_slice_cabac": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
     "avr_batch_add_slice_range": (c_int, [c_void_p, c_void_p, c_size_t]),
     "avr_batch_add_slice_codes": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "avr_batch_add_slice_cabac8": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
     "avr_batch_reserve_slice": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_size_t, POINTER(c_void_p)]),
     "avr_batch_submit": (c_int, [c_void_p]),
     "avr_batch_wait": (c_int, [c_void_p]),
@@ -332,6 +334,13 @@ class Batch:
         r = np.ascontiguousarray(recs, dtype=np.uint16)
         return _check(self._L.avr_batch_add_slice_range(self._h, r.ctypes.data, r.size))
 
+    def add_slice_cabac8(self, recs8, init_states) -> int:
+        """K1 from one-byte records (bin | dense selector << 1; selectors SEL8_BYPASS / SEL8_TERMINATE): half the bytes over PCIe."""
+        import numpy as np
+        r = np.ascontiguousarray(recs8, dtype=np.uint8)
+        s = np.ascontiguousarray(init_states, dtype=np.uint8)
+        return _check(self._L.avr_batch_add_slice_cabac8(self._h, r.ctypes.data, r.size, s.ctypes.data, s.size))
+
     def add_codes(self, codes) -> int:
         """K1 from resolved codes (one uint8 per bin: AVR_CODE_CONTEXT / _BYPASS / _TERMINATE)."""
         import numpy as np
@@ -345,7 +354,7 @@ class Batch:
         p = c_void_p()
         idx = _check(self._L.avr_batch_reserve_slice(self._h, kind, n, None if st is None else st.ctypes.data,
                                                      0 if st is None else st.size, ctypes.byref(p)))
-        ctype = ctypes.c_uint8 if kind == KIND_CABAC_CODES else ctypes.c_uint16
+        ctype = ctypes.c_uint8 if kind in (KIND_CABAC_CODES, KIND_CABAC8) else ctypes.c_uint16
         view = np.ctypeslib.as_array(ctypes.cast(p.value, POINTER(ctype)), shape=(n,)) if n else np.zeros(0, ctype)
         return idx, view
 

@@ -109,6 +109,7 @@ struct avr_batch {
     int device = 0;
     size_t max_slices = 0, max_bins = 0, total_bins = 0;
     int kind = -1;
+    bool recs8 = false;                     // the slices came as one-byte records (AVR_KIND_CABAC8); kind is AVR_KIND_CABAC
     size_t n_states = 0;
     bool ran = false;
     hipStream_t stream = nullptr;
@@ -126,6 +127,7 @@ struct avr_batch {
 
     // device side
     DevBuf<uint16_t> d_recs;
+    DevBuf<uint8_t> d_recs8;                // one-byte records as they came over PCIe (widened into d_recs on the device)
     DevBuf<uint4> d_tiles;
     DevBuf<uint64_t> d_rec_off, d_tile_off, d_out_off, d_dense_off;
     DevBuf<uint32_t> d_n_bins, d_order, d_out_len;
@@ -248,7 +250,7 @@ void avr_batch_destroy(avr_batch *b) {
     if (b->stream) (void)hipStreamSynchronize(b->stream);
     b->h_recs.release(); b->h_states.release(); b->h_out.release(); b->h_final.release();
     b->h_out_len.release(); b->h_status.release(); b->h_plan.release(); b->h_ndense.release();
-    b->d_recs.release(); b->d_tiles.release(); b->d_rec_off.release(); b->d_tile_off.release();
+    b->d_recs.release(); b->d_recs8.release(); b->d_tiles.release(); b->d_rec_off.release(); b->d_tile_off.release();
     b->d_out_off.release(); b->d_dense_off.release(); b->d_n_bins.release(); b->d_order.release();
     b->d_out_len.release(); b->d_status.release(); b->d_states.release(); b->d_final.release();
     b->d_out.release(); b->d_dense.release();
@@ -262,7 +264,7 @@ void avr_batch_destroy(avr_batch *b) {
 int avr_batch_reset(avr_batch *b) {
     if (!b) return fail(AVR_ERR_INVALID, "null batch");
     if (b->in_flight) return fail(AVR_ERR_INVALID, "batch is in flight; call avr_batch_wait first");
-    b->kind = -1; b->n_states = 0; b->ran = false; b->total_bins = 0;
+    b->kind = -1; b->recs8 = false; b->n_states = 0; b->ran = false; b->total_bins = 0;
     b->rec_off.assign(1, 0);
     b->n_bins.clear();
     b->dense_off.clear();
@@ -274,8 +276,15 @@ static int reserve_slice(avr_batch *b, int kind, size_t n, const uint8_t *init_s
     if (!b) return fail(AVR_ERR_INVALID, "null batch");
     if (b->in_flight) return fail(AVR_ERR_INVALID, "batch is in flight; call avr_batch_wait first");
     if (b->ran) return fail(AVR_ERR_INVALID, "batch already ran; call avr_batch_reset first");
-    if (kind != AVR_KIND_CABAC && kind != AVR_KIND_RANGE && kind != AVR_KIND_CABAC_CODES) return fail(AVR_ERR_INVALID, "unknown kind %d", kind);
-    if (b->kind >= 0 && b->kind != kind) return fail(AVR_ERR_INVALID, "a batch holds slices of one kind only");
+    if (kind != AVR_KIND_CABAC && kind != AVR_KIND_RANGE && kind != AVR_KIND_CABAC_CODES && kind != AVR_KIND_CABAC8)
+        return fail(AVR_ERR_INVALID, "unknown kind %d", kind);
+    // one-byte records are K1 records in another width: the batch is an AVR_KIND_CABAC batch whose staging buffer holds bytes
+    const bool recs8 = kind == AVR_KIND_CABAC8;
+    if (recs8) {
+        if (n_states > AVR_MAX_STATES8) return fail(AVR_ERR_INVALID, "n_states %zu > %d: one-byte records name at most %d contexts", n_states, AVR_MAX_STATES8, AVR_MAX_STATES8);
+        kind = AVR_KIND_CABAC;
+    }
+    if (b->kind >= 0 && (b->kind != kind || b->recs8 != recs8)) return fail(AVR_ERR_INVALID, "a batch holds slices of one kind only");
     if (n > 0xfffffff0u) return fail(AVR_ERR_INVALID, "slice too long");
     if (b->n_bins.size() >= b->max_slices) return fail(AVR_ERR_CAPACITY, "batch holds max_slices=%zu slices", b->max_slices);
     if (b->total_bins + n > b->max_bins) return fail(AVR_ERR_CAPACITY, "batch holds max_bins=%zu records", b->max_bins);
@@ -301,6 +310,14 @@ static int reserve_slice(avr_batch *b, int kind, size_t n, const uint8_t *init_s
         memset(dst + n, AVR_CODE_BYPASS(0), padded - n);         // the padding value of a resolved stream (bypass 0, never coded)
         b->rec_off.push_back(off + padded);
         *where = dst;
+    } else if (recs8) {
+        // one byte per record in the same pinned buffer, slice i at BYTE rec_off[i] (its records will be at record rec_off[i] on the
+        // device); what lies between a slice's last record and the next multiple of 8 is made a no-op by the widening kernel
+        const uint64_t padded = (uint64_t(n) + 7) & ~uint64_t(7);
+        uint8_t *dst = reinterpret_cast<uint8_t *>(b->h_recs.p) + off;
+        memset(dst + n, 0, padded - n);
+        b->rec_off.push_back(off + padded);
+        *where = dst;
     } else {
         const uint64_t padded = (uint64_t(n) + 7) & ~uint64_t(7);
         for (uint64_t i = n; i < padded; i++) b->h_recs.p[off + i] = kind == AVR_KIND_CABAC ? AVR_NOP_CABAC : AVR_NOP_RANGE;
@@ -310,6 +327,7 @@ static int reserve_slice(avr_batch *b, int kind, size_t n, const uint8_t *init_s
     b->total_bins += n;
     b->n_bins.push_back(uint32_t(n));
     b->kind = kind;
+    b->recs8 = recs8;
     return int(idx);
 }
 
@@ -331,6 +349,14 @@ int avr_batch_add_slice_range(avr_batch *b, const uint16_t *recs, size_t n) {
     void *dst = nullptr;
     const int idx = reserve_slice(b, AVR_KIND_RANGE, n, nullptr, 0, &dst);
     if (idx >= 0 && n) memcpy(dst, recs, n * sizeof(uint16_t));
+    return idx;
+}
+
+int avr_batch_add_slice_cabac8(avr_batch *b, const uint8_t *recs8, size_t n, const uint8_t *init_states, size_t n_states) {
+    if (!recs8 && n) return fail(AVR_ERR_INVALID, "null records");
+    void *dst = nullptr;
+    const int idx = reserve_slice(b, AVR_KIND_CABAC8, n, init_states, n_states, &dst);
+    if (idx >= 0 && n) memcpy(dst, recs8, n);
     return idx;
 }
 
@@ -435,7 +461,7 @@ static int submit_impl(avr_batch *b, bool use_hint) {
     b->last_path = chunked;
 
     int rc;
-    if ((rc = b->d_recs.reserve(total_recs)) || (!chunked && (rc = b->d_tiles.reserve(total_chunks))) ||
+    if ((rc = b->d_recs.reserve(total_recs)) || (b->recs8 && (rc = b->d_recs8.reserve(total_recs + 16))) || (!chunked && (rc = b->d_tiles.reserve(total_chunks))) ||
         (rc = b->d_rec_off.reserve(n + 1)) || (rc = b->d_tile_off.reserve(n_tiles + 1)) ||
         (rc = b->d_out_off.reserve(n + 1)) || (rc = b->d_dense_off.reserve(n + 1)) ||
         (rc = b->d_n_bins.reserve(n)) || (rc = b->d_order.reserve(n)) || (rc = b->d_out_len.reserve(n)) ||
@@ -454,7 +480,8 @@ static int submit_impl(avr_batch *b, bool use_hint) {
     b->hint_used = hint.rows;
     b->h_ndense.p[0] = b->h_ndense.p[1] = 0;
     AVR_HIP(hipEventRecord(b->ev[0], s));
-    AVR_HIP(hipMemcpyAsync(b->d_recs.p, b->h_recs.p, total_recs * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    if (b->recs8) AVR_HIP(hipMemcpyAsync(b->d_recs8.p, b->h_recs.p, total_recs, hipMemcpyHostToDevice, s));        // one byte a record
+    else AVR_HIP(hipMemcpyAsync(b->d_recs.p, b->h_recs.p, total_recs * sizeof(uint16_t), hipMemcpyHostToDevice, s));
     AVR_STAGE(b->d_rec_off.p, b->rec_off.data(), n + 1);
     AVR_STAGE(b->d_out_off.p, out_off.data(), n + 1);
     AVR_STAGE(b->d_n_bins.p, b->n_bins.data(), n);
@@ -465,6 +492,8 @@ static int submit_impl(avr_batch *b, bool use_hint) {
     if (cabac && ns) AVR_HIP(hipMemcpyAsync(b->d_states.p, b->h_states.p, n * ns, hipMemcpyHostToDevice, s));
     AVR_HIP(hipEventRecord(b->ev[1], s));
     AVR_HIP(hipMemsetAsync(b->d_status.p, 0, n * sizeof(int32_t), s));
+    if (b->recs8)                                                // ... widened into the records the kernels read: from here on an AVR_KIND_CABAC batch
+        AVR_HIP(avr::launch_expand_records8(s, b->d_recs8.p, b->d_rec_off.p, b->d_n_bins.p, n32, uint32_t(ns), total_recs, b->d_recs.p));
     // Both K1 paths renumber the batch onto the contexts it uses themselves (the intra-slice parallel kernels inside
     // their census pass, the one-lane-per-slice kernel through launch_cabac_encode): records and states go in as they are.
     if (chunked && !cabac) {
@@ -653,6 +682,7 @@ struct avr_multi {
     std::vector<int> devices;
     size_t max_slices = 0, max_bins = 0, total_bins = 0;
     int kind = -1;
+    bool recs8 = false;                     // the slices came as one-byte records (AVR_KIND_CABAC8); kind is AVR_KIND_CABAC
     size_t n_states = 0;
     bool ran = false;
     std::vector<uint8_t> store;              // the slices' records / codes, back to back (bytes)

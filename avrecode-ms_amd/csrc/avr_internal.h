@@ -91,6 +91,9 @@ hipError_t launch_synth_tiles(hipStream_t s, int workload, uint32_t scale, uint6
                               const uint64_t *tile_off, void *tiles, uint8_t *init_states,
                               uint32_t n_states);
 
+// one-byte K1 records (AVR_KIND_CABAC8) -> the two-byte records of the kernels; `total` = records of the batch (a multiple of 8)
+hipError_t launch_expand_records8(hipStream_t s, const uint8_t *in, const uint64_t *rec_off, const uint32_t *n_bins, uint32_t n_slices,
+                                  uint32_t n_states, uint64_t total, uint16_t *out);
 hipError_t launch_context_census(hipStream_t s, const uint16_t *recs, uint64_t n, uint32_t *bitmap);
 hipError_t launch_context_remap(hipStream_t s, uint16_t *recs, uint64_t n, const uint16_t *table);
 hipError_t launch_states_permute(hipStream_t s, const uint8_t *src, uint32_t n_src, uint8_t *dst, uint32_t n_dst,

@@ -314,7 +314,7 @@ struct CabacLaneNS : CabacLaneN {
 };
 
 constexpr uint32_t kCensusStride = 16;                           // the one-lane-per-slice kernel renumbers from a 1-in-16 sample
-constexpr uint32_t kK1Waves = 8;                                 // waves per workgroup (fewer when the state rows are large): they share the two tables
+constexpr uint32_t kK1Waves = 4;                                 // waves per workgroup (fewer when the state rows are large): they share the two tables
 constexpr uint32_t kK1MaxWaves = 16;
 
 // table / index: the dense renumbering of the batch's contexts (k_k1p_densemap), or null: contexts as the caller
@@ -781,6 +781,32 @@ __global__ __launch_bounds__(64) void k_synth_slices(
     rs.flush(chunks);
 }
 
+// One-byte K1 records (AVR_KIND_CABAC8: bin | dense selector << 1; include/avrecode_ms_amd.h) widened into the two-byte records every K1
+// kernel reads -- what the batch API does with a batch that came over PCIe in half the bytes.  One thread per 8 records: 8 bytes in,
+// 16 out, both coalesced; a slice's records past its n_bins (the staging buffer pads every slice to 8) become no-ops.  Slice i's bytes
+// are at byte rec_off[i] of `in`, its records at record rec_off[i] of `out`: the same offsets, a multiple of 8 each.
+__global__ __launch_bounds__(256) void k_expand_records8(const uint8_t *in, const uint64_t *rec_off, const uint32_t *n_bins, uint32_t n_slices,
+                                                         uint32_t n_states, uint64_t total, uint16_t *out) {
+    const uint64_t g = (uint64_t(blockIdx.x) * 256 + threadIdx.x) * 8;           // first of this thread's eight records
+    if (g >= total) return;
+    uint32_t lo = 0, hi = n_slices;                              // the slice g lies in: the last i with rec_off[i] <= g
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rec_off[mid] <= g) lo = mid; else hi = mid; }
+    const uint64_t first = g - rec_off[lo];
+    const uint32_t n = n_bins[lo];
+    const uint2 v = *reinterpret_cast<const uint2 *>(in + g);
+    const uint32_t w[2] = {v.x, v.y};
+    uint32_t o[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xffu, sel8 = b >> 1;
+        uint32_t sel = sel8 == AVR_SEL8_BYPASS ? AVR_SEL_BYPASS : sel8 == AVR_SEL8_TERMINATE ? AVR_SEL_TERMINATE : sel8 < n_states ? sel8 : 1027u;
+        uint32_t rec = (sel << 1) | (b & 1u);
+        if (first + j >= n) rec = AVR_NOP_CABAC;
+        if (j & 1) o[j >> 1] |= rec << 16; else o[j >> 1] = rec;
+    }
+    *reinterpret_cast<uint4 *>(out + g) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // ------------------------------------------------------------------ launchers
 
 // The renumbering's scratch (4.25 KiB: used[32] + n_dense | table[1024] | index[1024]): one per (device, stream), made on
@@ -950,6 +976,14 @@ hipError_t launch_synth_tiles(hipStream_t s, int workload, uint32_t scale, uint6
     hipLaunchKernelGGL(k_synth_tiles, dim3((n_slices + 63) / 64), dim3(64), 0, s, workload, scale, seed,
                        first_slice, kind, n_slices, order, tile_off, reinterpret_cast<uint4 *>(tiles),
                        init_states, n_states);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_records8(hipStream_t s, const uint8_t *in, const uint64_t *rec_off, const uint32_t *n_bins, uint32_t n_slices,
+                                  uint32_t n_states, uint64_t total, uint16_t *out) {
+    if (n_slices == 0 || total == 0) return hipSuccess;
+    const uint64_t threads = total / 8;
+    hipLaunchKernelGGL(k_expand_records8, dim3(uint32_t((threads + 255) / 256)), dim3(256), 0, s, in, rec_off, n_bins, n_slices, n_states, total, out);
     return hipGetLastError();
 }
 

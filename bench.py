@@ -191,7 +191,7 @@ def cpu_baseline(avr, workload, kind, n_slices, first_slice, gpu_bytes_of, budge
     return res
 
 
-def e2e_block(avr, workload, kind, n_slices, first_slice, device, rounds=12, objects=3):
+def e2e_block(avr, workload, kind, n_slices, first_slice, device, rounds=12, objects=3, records8=False):
     """PCIe-inclusive rate of the batch API (what test.cpp:52-54 of the reference reports: end-to-end bytes per second): host
     records in pinned memory in, host bytes out, `objects` avr_batch objects used in turn (submit / wait), so that one
     batch's H2D runs under another's kernels.  Never `value`: the bench line's value has its inputs resident in HBM."""
@@ -200,13 +200,30 @@ def e2e_block(avr, workload, kind, n_slices, first_slice, device, rounds=12, obj
     m = min(m, 16384)
     recs, states = gen(kind)
     total_bins = int(nb[:m].astype(np.int64).sum())
+    n_ctx8 = None
+    if records8:
+        # what the recorder of INTEGRATION.md ships when a file has at most 126 contexts: ids dense by first appearance, one byte a record
+        sel = (recs[:int(roff[m])] >> 1).astype(np.int64)
+        ctx, first = np.unique(sel[sel < 1024], return_index=True)
+        ctx = ctx[np.argsort(first)]
+        n_ctx8 = int(ctx.size)
+        if n_ctx8 > avr.MAX_STATES8:
+            return {"skipped": f"{n_ctx8} contexts: more than one-byte records can name"}
+        lut = np.full(1026, 255, dtype=np.int64)
+        lut[ctx] = np.arange(n_ctx8)
+        lut[1024], lut[1025] = avr.SEL8_BYPASS, avr.SEL8_TERMINATE
+        recs = ((lut[sel] << 1) | (recs[:int(roff[m])] & 1)).astype(np.uint8)
+        states = np.ascontiguousarray(states.reshape(-1, cfg.n_states)[:, ctx]).reshape(-1)
+    ns = n_ctx8 if records8 else cfg.n_states
     bs = [avr.Batch(device, m, total_bins + 8) for _ in range(objects)]
     try:
         for b in bs:
             for i in range(m):
                 r = recs[int(roff[i]):int(roff[i + 1])]
-                if kind == avr.KIND_CABAC:
-                    b.add_slice_cabac(r, states[i * cfg.n_states:(i + 1) * cfg.n_states])
+                if records8:
+                    b.add_slice_cabac8(r, states[i * ns:(i + 1) * ns])
+                elif kind == avr.KIND_CABAC:
+                    b.add_slice_cabac(r, states[i * ns:(i + 1) * ns])
                 else:
                     b.add_slice_range(r)
         for b in bs:                                         # first run of an object (it asks the device for the context count)
@@ -226,7 +243,8 @@ def e2e_block(avr, workload, kind, n_slices, first_slice, device, rounds=12, obj
             b.close()
     return {"value": rounds * out_bytes / t, "unit": "bytes/s", "ms_per_batch": 1e3 * t / rounds, "slices_per_batch": m,
             "bins_per_batch": total_bins, "h264_bytes_per_batch": out_bytes, "batch_objects": objects, "rounds": rounds,
-            "input": "uint16 records in pinned host memory (2 B per bin)", "output": "coded bytes in host memory",
+            "input": (f"one-byte records (bin | dense selector << 1, {n_ctx8} contexts) in pinned host memory (1 B per bin)" if records8
+                      else "uint16 records in pinned host memory (2 B per bin)"), "output": "coded bytes in host memory",
             "h2d_ms_alone": tm["h2d_ms"], "note": "PCIe-inclusive; never the bench line's value"}
 
 
@@ -427,6 +445,8 @@ def main():
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         if world == 1 and not args.no_e2e and args.records == "bins":
             line["e2e"] = e2e_block(avr, args.workload, kind, n_slices, first, local_rank)
+            if kind == avr.KIND_CABAC:                           # the same batches as one-byte records (AVR_KIND_CABAC8): half the bytes over PCIe
+                line["e2e_cabac8"] = e2e_block(avr, args.workload, kind, n_slices, first, local_rank, records8=True)
         print(json.dumps(line), flush=True)
         if status_bad or line.get("cpu_baseline", {}).get("parity_vs_gpu") == "MISMATCH":
             failed = True

@@ -88,6 +88,15 @@ extern "C" {
 #define AVR_KIND_CABAC 0         /* K1: cabac::encoder           (cabac_code.h:26-82)   */
 #define AVR_KIND_RANGE 1         /* K2: recoded_code::encoder    (recode.cpp:322-323)   */
 #define AVR_KIND_CABAC_CODES 2   /* K1 from resolved codes: one byte per bin, see avr_batch_add_slice_codes */
+#define AVR_KIND_CABAC8 3        /* K1 from ONE-BYTE records (bin, dense selector), see avr_batch_add_slice_cabac8 */
+
+/* One-byte K1 records (AVR_KIND_CABAC8): bit 0 = the bin, bits 1..7 = a dense selector -- 0 .. 125 the slice's contexts in the
+ * order the recorder met them (its ids are dense by first appearance already: INTEGRATION.md), AVR_SEL8_BYPASS, AVR_SEL8_TERMINATE.
+ * What the record stands for is what the two-byte record stands for (recode.cpp:1442-1481); a stream with more than 126 contexts
+ * keeps the two-byte form. */
+#define AVR_SEL8_BYPASS     126
+#define AVR_SEL8_TERMINATE  127
+#define AVR_MAX_STATES8     126
 
 const char *avr_last_error(void);
 const char *avr_version(void);
@@ -127,8 +136,15 @@ int avr_batch_add_slice_range(avr_batch *b, const uint16_t *recs, size_t n);
  * A batch of few, long slices is coded by the intra-slice parallel kernels (K1p phases B-D), a batch of
  * many short ones by one lane per slice (k_cabac_encode_codes); either way every slice is coded. */
 int avr_batch_add_slice_codes(avr_batch *b, const uint8_t *codes, size_t n);
-/* Zero-copy form of the three calls above: room for a slice of n elements (uint16_t records for AVR_KIND_CABAC /
- * AVR_KIND_RANGE, uint8_t codes for AVR_KIND_CABAC_CODES) in the batch's pinned staging buffer, which the H2D copy
+/* K1 from ONE-BYTE records (AVR_KIND_CABAC8, above): the same slice as avr_batch_add_slice_cabac would take, in half the bytes
+ * over PCIe -- which is what bounds the batch API end to end (2 B per bin against 0.1 B of output).  init_states: n_states <=
+ * AVR_MAX_STATES8 bytes, indexed by the dense selector.  On the device the records are widened into the two-byte form
+ * (k_expand_records8) and take the path of avr_batch_add_slice_cabac from there: same kernels, same bytes, same statuses -- a
+ * selector >= n_states that is neither bypass nor terminate comes back as AVR_SLICE_BAD_RECORD. */
+int avr_batch_add_slice_cabac8(avr_batch *b, const uint8_t *recs8, size_t n,
+                               const uint8_t *init_states, size_t n_states);
+/* Zero-copy form of the four calls above: room for a slice of n elements (uint16_t records for AVR_KIND_CABAC /
+ * AVR_KIND_RANGE, uint8_t codes for AVR_KIND_CABAC_CODES, uint8_t records for AVR_KIND_CABAC8) in the batch's pinned staging buffer, which the H2D copy
  * reads directly; the caller writes exactly n elements to *buffer before avr_batch_submit / avr_batch_run (the padding
  * after them is already in place).  init_states / n_states as for avr_batch_add_slice_cabac (copied now), ignored
  * for the other kinds.  A recorder that appends here saves one pass over its records.  Returns the slice index. */

@@ -65,3 +65,14 @@ def test_context_state_machine_is_monotone():
         assert all(0 <= x < 126 for x in succ)               # pStateIdx 63 is never entered
         assert all(succ[i] <= succ[i + 1] for i in range(125)), b
     assert all(nxt(s, b) == s for s in (126, 127) for b in (0, 1)) or True   # (pStateIdx 63: the kernels never move it)
+
+
+def test_one_byte_records_are_refused_where_they_cannot_name_the_contexts(avr):
+    """AVR_KIND_CABAC8 names at most 126 contexts (7 selector bits, two of the 128 values taken by bypass and terminate): the argument
+    checks of avr_batch_add_slice_cabac8 / avr_batch_reserve_slice run before anything touches a device -- here, where there is none,
+    a batch cannot even be created, so only the constants of the two record widths are compared."""
+    assert (avr.SEL8_BYPASS, avr.SEL8_TERMINATE, avr.MAX_STATES8, avr.KIND_CABAC8) == (126, 127, 126, 3)
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "avrecode_ms_amd.h")).read()
+    for name, value in (("AVR_SEL8_BYPASS", 126), ("AVR_SEL8_TERMINATE", 127), ("AVR_MAX_STATES8", 126), ("AVR_KIND_CABAC8", 3)):
+        assert int(re.search(r"#define\s+%s\s+(\d+)" % name, hdr).group(1)) == value

@@ -92,6 +92,50 @@ def test_cabac_random_ragged(avr, oracle, n_states, form, hooks):
         assert got == oracle.cabac_encode(recs, st), f"slice {i} n={len(recs)}"
 
 
+
+def to_records8(recs):
+    """Two-byte K1 records (selectors below 126, bypass, terminate) as the one-byte records of AVR_KIND_CABAC8."""
+    sel = (recs >> 1).astype(np.int64)
+    sel8 = np.where(sel == 1024, 126, np.where(sel == 1025, 127, sel))
+    assert ((sel8 >= 0) & (sel8 < 128)).all()
+    return ((sel8 << 1) | (recs & 1)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("n_states,long_slices", [(5, False), (126, False), (86, True)])
+def test_cabac8_one_byte_records_code_what_two_byte_records_code(avr, oracle, n_states, long_slices):
+    """AVR_KIND_CABAC8 (the record of recode.cpp:1442-1481 in one byte: bin | dense selector << 1): the same slices through
+    avr_batch_add_slice_cabac8 and through avr_batch_add_slice_cabac give the same bytes, final states and statuses, and both equal
+    the oracle -- for batches the one-lane-per-slice kernel takes (many short slices, empty and terminate-only ones among them) and for
+    one the intra-slice parallel kernels take (few long ones); a selector that names no context of the slice is a bad record."""
+    rng = np.random.default_rng(800 + n_states)
+    if long_slices:
+        slices = [oracle_lib.random_cabac_stream(rng, int(rng.integers(20000, 60000)), n_states) for _ in range(9)]
+    else:
+        slices = [oracle_lib.random_cabac_stream(rng, int(rng.integers(0, 2500)) if i % 6 else int(rng.integers(0, 9)), n_states,
+                                                 terminate=(i % 4 != 0)) for i in range(150)]
+        slices.append((np.zeros(0, dtype=np.uint16), np.zeros(n_states, dtype=np.uint8)))
+        slices.append((np.array([TERM1], dtype=np.uint16), np.zeros(n_states, dtype=np.uint8)))
+    total = sum(len(r) for r, _ in slices) + 8
+    with avr.Batch(0, len(slices) + 1, total + 64) as b8, avr.Batch(0, len(slices) + 1, total + 64) as b16:
+        for r, st in slices:
+            b8.add_slice_cabac8(to_records8(r), st)
+            b16.add_slice_cabac(r, st)
+        b8.run(); b16.run()
+        assert b8.run_info()["chunked"] == b16.run_info()["chunked"] == int(long_slices)
+        for i, (r, st) in enumerate(slices):
+            want = oracle.cabac_encode(r, st)
+            got8 = (b8.get(i)[0], b8.get_states(i), b8.get(i)[1])
+            assert got8 == want == (b16.get(i)[0], b16.get_states(i), b16.get(i)[1]), f"slice {i} n={len(r)}"
+    if n_states < 126:                                       # selector n_states: neither a context of the slice nor bypass / terminate
+        bad = np.array([(n_states << 1) | 1, (127 << 1) | 1], dtype=np.uint8)
+        with avr.Batch(0, 4, 64) as b:
+            b.add_slice_cabac8(bad, np.zeros(n_states, dtype=np.uint8))
+            b.add_slice_cabac8(to_records8(slices[0][0]), slices[0][1])
+            b.run()
+            assert b.get(0)[1] == 3                          # AVR_SLICE_BAD_RECORD
+            assert (b.get(1)[0], b.get(1)[1]) == (oracle.cabac_encode(*slices[0])[0], 0)
+
+
 @pytest.mark.parametrize("stride", [1, 16, 1000003])
 def test_cabac_census_sample_and_hand_back(avr, oracle, stride, hooks):
     """The one-lane-per-slice kernel renumbers the batch's contexts from a SAMPLE of the records (every 16th chunk); a
