@@ -128,7 +128,7 @@ def test_cabac8_one_byte_records_code_what_two_byte_records_code(avr, oracle, n_
             assert got8 == want == (b16.get(i)[0], b16.get_states(i), b16.get(i)[1]), f"slice {i} n={len(r)}"
     if n_states < 126:                                       # selector n_states: neither a context of the slice nor bypass / terminate
         bad = np.array([(n_states << 1) | 1, (127 << 1) | 1], dtype=np.uint8)
-        with avr.Batch(0, 4, 64) as b:
+        with avr.Batch(0, 4, len(slices[0][0]) + 64) as b:
             b.add_slice_cabac8(bad, np.zeros(n_states, dtype=np.uint8))
             b.add_slice_cabac8(to_records8(slices[0][0]), slices[0][1])
             b.run()
