@@ -917,6 +917,9 @@ class h264_stream_decoder : public host::stream_decoder {
     // recorders queue them behind the block's nonzero count.  Off by default, as in the reference's fork ("Not called").
     // Both directions of a file must agree on it (the container does not say which model wrote it).
     bool residual_hooks = false;
+    // Threads for the payload dry runs (pass 2 of decode_video): 0 = AVR_PARSE_THREADS if that is a number (clamped to 1 .. 16), else the
+    // host's cores (at most 16).  A caller that already runs one decoder per thread (recode test <dir>) sets 1.
+    unsigned dry_run_threads = 0;
 
     void expect_payload_questions() override { answers_ahead_ = true; }
 
@@ -965,9 +968,15 @@ class h264_stream_decoder : public host::stream_decoder {
                 for (size_t i; (i = next.fetch_add(1)) < jobs.size();)
                     if (jobs[i].header_ok) jobs[i].decodes = dry_run(jobs[i], residual_hooks, &jobs[i].reason, &scratch) ? 1 : 0;
             };
-            const char *forced = getenv("AVR_PARSE_THREADS");              // (the CLI's environment, like AVR_DEVICE: default = the host's cores, at most 16)
-            const unsigned hw = forced ? unsigned(atoi(forced)) : std::thread::hardware_concurrency();
-            const size_t n_threads = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw ? hw : 4, 16), jobs.size()));
+            unsigned want = dry_run_threads;
+            if (!want) {                                         // (the CLI's environment, like AVR_DEVICE; anything that is not a number is ignored)
+                const char *forced = getenv("AVR_PARSE_THREADS");
+                char *end = nullptr;
+                const long v = forced ? strtol(forced, &end, 10) : 0;
+                if (forced && end != forced && *end == 0) want = unsigned(std::min<long>(std::max<long>(v, 1), 16));
+            }
+            if (!want) { const unsigned hw = std::thread::hardware_concurrency(); want = std::min<unsigned>(hw ? hw : 4, 16); }
+            const size_t n_threads = std::max<size_t>(1, std::min<size_t>(want, jobs.size()));
             std::vector<std::thread> pool;
             for (size_t t = 1; t < n_threads; t++) pool.emplace_back(work);
             work();
@@ -975,7 +984,10 @@ class h264_stream_decoder : public host::stream_decoder {
         }
         // Pass 3, in stream order: the hooks.
         host::phase_timer timer("parse: hooks in stream order");
-        for (slice_job &j : jobs) slice(h, j);
+        for (slice_job &j : jobs) {
+            slice(h, j);
+            std::vector<uint8_t>().swap(j.rbsp);                 // one slice's unescaped bytes at a time from here on, not a second copy of the file
+        }
     }
 
     // compressor asks before it commits to the slice just offered: does the payload parse to its end?  (On the way back

@@ -145,15 +145,45 @@ class compressor {                                       // recode.cpp:1109-1316
     compressor(const std::string &original_bytes, int device = 0) : original_(original_bytes), device_(device) {}
 
     std::string run(stream_decoder *d) {                 // :1122-1132
+        prepare(d);
+        { phase_timer t("compress: GPU batch (K2)"); code_pending(); }
+        return finish();
+    }
+    // run() in three steps, so that a caller with several files (recode test <dir>, test.cpp:113-148) can code the slices of all of
+    // them in one GPU batch: prepare() = everything the host does up to the coding (parse, hooks, recorders), add_to() / take_from() =
+    // this file's slices into and out of a batch the caller owns, finish() = the final literal and the container's bytes.
+    void prepare(stream_decoder *d) {
         decoder_ = d;
         d->expect_payload_questions();
         hooks h = hook_adapter<compressor>::make(this);
-        {
-            phase_timer t("compress: parse + record");
-            d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<compressor *>(o)->read_packet(buf, size); }, this);
-            cabac_contexts.clear();
+        phase_timer t("compress: parse + record");
+        d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<compressor *>(o)->read_packet(buf, size); }, this);
+        cabac_contexts.clear();
+    }
+    size_t pending_slices() const { return pending_.size(); }
+    size_t pending_bins() const { size_t bins = 0; for (auto &p : pending_) bins += p.recs.size(); return bins; }
+    void add_to(avr_batch *b) {                          // the slice indices the batch hands out are consecutive: the first one is kept
+        first_in_batch_ = -1;
+        for (auto &p : pending_) {
+            const int idx = avr_batch_add_slice_range(b, p.recs.data(), p.recs.size());
+            gpu_check(idx);
+            if (first_in_batch_ < 0) first_in_batch_ = idx;
+            std::vector<uint16_t>().swap(p.recs);        // the batch has its copy
         }
-        { phase_timer t("compress: GPU batch (K2)"); code_pending(); }
+    }
+    void take_from(avr_batch *b) {
+        for (size_t i = 0; i < pending_.size(); i++) {
+            const uint8_t *bytes; size_t len; int status;
+            gpu_check(avr_batch_get(b, size_t(first_in_batch_) + i, &bytes, &len, &status));
+            if (status == AVR_SLICE_ZERO_PROB) throw std::runtime_error("Encoder error: emitted a zero-probability symbol.");   // arithmetic_code.h:117
+            if (status != AVR_SLICE_OK) throw std::runtime_error("avr: slice status " + std::to_string(status));
+            Block &blk = out_.block[pending_[i].block];
+            blk.has_cabac = true;                        // out->set_cabac, recode.cpp:1101
+            blk.cabac.assign(reinterpret_cast<const char *>(bytes), len);
+        }
+        pending_.clear();
+    }
+    std::string finish() {
         Block final_literal;
         final_literal.has_literal = true;
         final_literal.literal = original_.substr(prev_coded_block_end_);
@@ -252,24 +282,14 @@ class compressor {                                       // recode.cpp:1109-1316
 
     void code_pending() {                                // one K2 batch for the whole file
         if (pending_.empty()) return;
-        size_t bins = 0;
-        for (auto &p : pending_) bins += p.recs.size();
-        batch_holder bh(device_, pending_.size(), bins + 8);
-        for (auto &p : pending_) gpu_check(avr_batch_add_slice_range(bh.b, p.recs.data(), p.recs.size()));
+        batch_holder bh(device_, pending_.size(), pending_bins() + 8);
+        add_to(bh.b);
         gpu_check(avr_batch_run(bh.b));
-        for (size_t i = 0; i < pending_.size(); i++) {
-            const uint8_t *bytes; size_t len; int status;
-            gpu_check(avr_batch_get(bh.b, i, &bytes, &len, &status));
-            if (status == AVR_SLICE_ZERO_PROB) throw std::runtime_error("Encoder error: emitted a zero-probability symbol.");   // arithmetic_code.h:117
-            if (status != AVR_SLICE_OK) throw std::runtime_error("avr: slice status " + std::to_string(status));
-            Block &b = out_.block[pending_[i].block];
-            b.has_cabac = true;                          // out->set_cabac, recode.cpp:1101
-            b.cabac.assign(reinterpret_cast<const char *>(bytes), len);
-        }
-        pending_.clear();
+        take_from(bh.b);
     }
 
     struct pending { int block; std::vector<uint16_t> recs; };
+    int first_in_batch_ = -1;
     std::string original_;
     int device_;
     int read_offset_ = 0, prev_coded_block_end_ = 0;
@@ -296,15 +316,43 @@ class decompressor {                                     // recode.cpp:1319-1598
     }
 
     std::string run(stream_decoder *d) {                 // :1345-1364
+        prepare(d);
+        { phase_timer t("decompress: GPU batch (K1)"); code_pending(); }
+        return finish();
+    }
+    // run() in three steps, as compressor's: prepare() = the range decoder (K3) and the parse, recording resolved codes; add_to() /
+    // take_from() = this file's slices into and out of a batch the caller owns; finish() = tail patches and the file's bytes.
+    void prepare(stream_decoder *d) {
         blocks_.clear();
         blocks_.resize(in_.block.size());
         hooks h = hook_adapter<decompressor>::make(this);
-        {
-            phase_timer t("decompress: K3 + parse");
-            d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<decompressor *>(o)->read_packet(buf, size); }, this);
-            cabac_contexts.clear();
+        phase_timer t("decompress: K3 + parse");
+        d->decode_video(&h, [](void *o, uint8_t *buf, int size) { return static_cast<decompressor *>(o)->read_packet(buf, size); }, this);
+        cabac_contexts.clear();
+    }
+    size_t pending_slices() const { return pending_.size(); }
+    size_t pending_bins() const { size_t bins = 0; for (auto &p : pending_) bins += p.codes.size(); return bins; }
+    void add_to(avr_batch *b) {
+        first_in_batch_ = -1;
+        for (auto &p : pending_) {
+            const int idx = avr_batch_add_slice_codes(b, p.codes.data(), p.codes.size());
+            gpu_check(idx);
+            if (first_in_batch_ < 0) first_in_batch_ = idx;
+            std::vector<uint8_t>().swap(p.codes);
         }
-        { phase_timer t("decompress: GPU batch (K1)"); code_pending(); }
+    }
+    void take_from(avr_batch *b) {
+        for (size_t i = 0; i < pending_.size(); i++) {
+            const uint8_t *bytes; size_t len; int status;
+            gpu_check(avr_batch_get(b, size_t(first_in_batch_) + i, &bytes, &len, &status));
+            if (status != AVR_SLICE_OK) throw std::runtime_error("avr: slice status " + std::to_string(status));
+            len = avr_drop_stop_byte(bytes, len);        // cabac_decoder::finish, recode.cpp:1508-1512
+            blocks_[pending_[i].index].out_bytes.assign(reinterpret_cast<const char *>(bytes), len);
+            blocks_[pending_[i].index].done = true;
+        }
+        pending_.clear();
+    }
+    std::string finish() {
         std::string out;
         for (auto &block : blocks_) {
             if (!block.done) throw std::runtime_error("Not all blocks were decoded.");
@@ -429,23 +477,14 @@ class decompressor {                                     // recode.cpp:1319-1598
     // shipped as one byte and the GPU skips working the states out again.
     void code_pending() {
         if (pending_.empty()) return;
-        size_t bins = 0;
-        for (auto &p : pending_) bins += p.codes.size();
-        batch_holder bh(device_, pending_.size(), bins + 16 * pending_.size() + 64);
-        for (auto &p : pending_) gpu_check(avr_batch_add_slice_codes(bh.b, p.codes.data(), p.codes.size()));
+        batch_holder bh(device_, pending_.size(), pending_bins() + 16 * pending_.size() + 64);
+        add_to(bh.b);
         gpu_check(avr_batch_run(bh.b));
-        for (size_t i = 0; i < pending_.size(); i++) {
-            const uint8_t *bytes; size_t len; int status;
-            gpu_check(avr_batch_get(bh.b, i, &bytes, &len, &status));
-            if (status != AVR_SLICE_OK) throw std::runtime_error("avr: slice status " + std::to_string(status));
-            len = avr_drop_stop_byte(bytes, len);        // cabac_decoder::finish, recode.cpp:1508-1512
-            blocks_[pending_[i].index].out_bytes.assign(reinterpret_cast<const char *>(bytes), len);
-            blocks_[pending_[i].index].done = true;
-        }
-        pending_.clear();
+        take_from(bh.b);
     }
 
     struct pending { int index; std::vector<uint8_t> codes; };
+    int first_in_batch_ = -1;
     int device_;
     Recoded in_;
     int read_index_ = 0;                                 // blocks the reader has opened

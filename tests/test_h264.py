@@ -190,3 +190,43 @@ def test_recode_test_directory(recode, tmp_path):
     assert log.count("Compress-decompress roundtrip succeeded:") == len(CLIPS)
     for name in CLIPS:
         assert (tmp_path / "output" / name).stat().st_size > 0
+
+
+@pytest.mark.gpu
+def test_recode_test_directory_batches_across_files(recode, tmp_path):
+    """`recode test <dir>` over a directory of 16 copies of each of the image's two clips: the files of the directory go through the two
+    directions together -- host sides one file per thread, the slices of ALL files in one GPU batch per direction (K2 in, K1 out) -- and
+    write exactly the files the reference's loop writes (AVR_TEST_SEQUENTIAL=1: a file at a time, a batch per file and direction, as
+    rounds 1-3 ran it); every output file decompresses back to its clip.  The two wall times go to gpurun_out/ (profiles/r04_cli_timing.txt)."""
+    import time
+    a, b = tmp_path / "batched", tmp_path / "sequential"
+    for d in (a, b):
+        d.mkdir()
+        for k in range(16):
+            for name in CLIPS:
+                shutil.copy(clip(name), d / f"{k:02d}_{name}")
+    t0 = time.perf_counter()
+    out = subprocess.run([recode, "test", str(a)], capture_output=True, text=True, timeout=1800)
+    t_batched = time.perf_counter() - t0
+    assert out.returncode == 0 and "failed on" not in out.stdout, out.stderr + out.stdout
+    t0 = time.perf_counter()
+    seq = subprocess.run([recode, "test", str(b)], capture_output=True, text=True, timeout=1800, env=dict(os.environ, AVR_TEST_SEQUENTIAL="1"))
+    t_seq = time.perf_counter() - t0
+    assert seq.returncode == 0 and "failed on" not in seq.stdout, seq.stderr + seq.stdout
+    names = sorted(p.name for p in a.iterdir() if p.is_file())
+    assert len(names) == 16 * len(CLIPS)
+    for name in names:
+        got, want = (a / "output" / name).read_bytes(), (b / "output" / name).read_bytes()
+        assert got == want and len(got) > 0, name
+    for name in names[:2] + names[-2:]:                      # ... and they are what `recode decompress` turns back into the clip
+        back = subprocess.run([recode, "decompress", str(a / "output" / name)], capture_output=True, timeout=600)
+        assert back.returncode == 0 and back.stdout == (a / name).read_bytes(), name
+    rows = (a / "output" / "metrics.csv").read_text().strip().splitlines()
+    assert len(rows) == 1 + len(names)
+    assert (a / "output" / "log.txt").read_text().count("Compress-decompress roundtrip succeeded:") == len(names)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.path.isdir(os.path.join(root, "gpurun_out")):
+        with open(os.path.join(root, "gpurun_out", "cli_directory_timing.txt"), "w") as f:
+            f.write(f"recode test <dir>, {len(names)} files ({sum((a / n).stat().st_size for n in names)} bytes): "
+                    f"batched across files {t_batched:.2f} s, a file at a time {t_seq:.2f} s, ratio {t_seq / t_batched:.2f}\n")
+    assert t_batched < t_seq

@@ -125,3 +125,29 @@ def test_crafted_headers_are_rejected_not_dereferenced(recode_asan, tmp_path, ca
         run = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=120)
         assert run.returncode == 0 and "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-2000:]
     assert back.read_bytes() == CASES[case]
+
+
+def test_directory_driver_on_files_with_nothing_to_code(recode_asan, tmp_path):
+    """`recode test <dir>` (test.cpp:113-148) on a directory of the crafted streams, three copies each: the driver that takes the
+    directory's files through both directions together (host side one file per thread, one GPU batch per direction for all of them)
+    writes, file for file, what the reference's loop writes (AVR_TEST_SEQUENTIAL=1).  Nothing in these files parses, so nothing is
+    coded and no GPU is needed: this is the threads, the windows (AVR_TEST_WINDOW=4: several of them) and the bookkeeping, under ASan +
+    UBSan; the same comparison on real clips, with the batches, is tests/test_h264.py::test_recode_test_directory_batches_across_files."""
+    a, b = tmp_path / "together", tmp_path / "one_by_one"
+    for d in (a, b):
+        d.mkdir()
+        for k in range(3):
+            for case, data in CASES.items():
+                (d / f"{k}_{case}.h264").write_bytes(data)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", AVR_TEST_WINDOW="4")
+    for d, extra in ((a, {}), (b, {"AVR_TEST_SEQUENTIAL": "1"})):
+        run = subprocess.run([recode_asan, "test", str(d)], capture_output=True, text=True, env=dict(env, **extra), timeout=600)
+        assert run.returncode == 0 and "failed on" not in run.stdout, run.stdout + run.stderr[-2000:]
+        assert "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-2000:]
+    names = sorted(p.name for p in a.iterdir() if p.is_file())
+    assert len(names) == 3 * len(CASES)
+    for name in names:
+        assert (a / "output" / name).read_bytes() == (b / "output" / name).read_bytes() and (a / "output" / name).stat().st_size > 0, name
+    rows = (a / "output" / "metrics.csv").read_text().strip().splitlines()
+    assert rows[0] == (b / "output" / "metrics.csv").read_text().splitlines()[0] and len(rows) == 1 + len(names)
+    assert (a / "output" / "log.txt").read_text().count("Compress-decompress roundtrip succeeded:") == len(names)
