@@ -257,7 +257,7 @@ void avr_batch_destroy(avr_batch *b) {
     b->d_res_off.release(); b->d_dig_off.release(); b->d_chunk_base.release(); b->d_chunk_slice.release();
     b->d_blk_base.release(); b->d_blk_slice.release(); b->d_workspace.release();
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
-    if (b->stream) (void)hipStreamDestroy(b->stream);
+    if (b->stream) { avr::forget_stream(b->stream); (void)hipStreamDestroy(b->stream); }
     delete b;
 }
 

@@ -69,6 +69,9 @@ inline bool no_hint() { return test_hooks().no_hint || env().no_hint; }
 //     caller that finds it non-zero calls launch_k1p_retry with the arguments of launch_k1p.
 struct DenseHint { uint32_t rows; uint32_t *host_count; uint32_t *host_retry; };
 
+// what the library keeps per (device, stream) -- the renumbering's scratch, K2p's second stream and events -- released: call before the stream is destroyed
+void forget_stream(hipStream_t s);
+
 hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,
                                const uint8_t *init_states, uint32_t n_states, uint8_t *out,

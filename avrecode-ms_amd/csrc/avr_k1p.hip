@@ -595,7 +595,10 @@ __global__ __launch_bounds__(64 * kSegWaves) void k_k1p_chain_seg(Plan p, uint32
         w0 = w1; w1 = w2;
     }
     SegSummary o;
-    o.bits[0] = bits0; o.bits[1] = bits1; o.n_bins = n_bins; o.exit_state = uint8_t(st[0]); o.met = st[0] == st[1]; o.met_chunk = uint16_t(met_chunk < 0xffffu ? met_chunk : 0xffffu);
+    // (met_chunk has 16 bits: a meeting point beyond chunk 65 534 of the segment -- a slice of half a gigabin -- is reported as "did not meet",
+    // which k_k1p_chain_fix answers by walking the whole segment again: slower for that pair, never wrong)
+    o.bits[0] = bits0; o.bits[1] = bits1; o.n_bins = n_bins; o.exit_state = uint8_t(st[0]); o.met = st[0] == st[1] && met_chunk < 0xffffu;
+    o.met_chunk = uint16_t(met_chunk < 0xffffu ? met_chunk : 0xffffu);
     summ[(size_t(L.s) * nk + k) * kChainSegs + L.seg] = o;
 }
 

@@ -30,6 +30,15 @@ namespace {
 
 struct U4 { uint32_t x, y, z, w; };
 
+// A slice's status is written from two streams at once while pass 2 of one segment runs beside pass 1 of the next: pass 1 finds bad
+// records and hands slices over (RETRY_SERIAL), pass 2 finds regions too small (OVERFLOW).  So that what a slice reports does not
+// depend on which came first: a bad record overwrites anything; OVERFLOW and RETRY_SERIAL only replace "no error yet" (a slice handed
+// over is walked again from its start and finds its overflow again; one in error already is left alone).
+__device__ __forceinline__ void note_status(int32_t *status, int32_t code) {
+    if (code == AVR_SLICE_BAD_RECORD) atomicExch(status, code);
+    else atomicCAS(status, AVR_SLICE_OK, code);
+}
+
 struct K2Plan {
     const uint16_t *recs;
     const uint64_t *rec_off;
@@ -243,8 +252,10 @@ __device__ __forceinline__ void ranges_fp_body(uint32_t block, uint32_t long_chu
         fin_range[s] = fp_to_u64(rg);
         fin_pos[s] = pos8 >> 3;
     }
-    if (high & 0x80008000u) status[s] = AVR_SLICE_BAD_RECORD;
-    else if (vmin_hi < kTwo39Hi) status[s] = AVR_SLICE_RETRY_SERIAL;   // the integer form walks it again, from the start
+    // (pass 2 of an earlier segment writes the same word from the second stream: a bad record wins over everything, and a slice that is
+    // in error already is not asked to be walked again -- see note_status)
+    if (high & 0x80008000u) note_status(&status[s], AVR_SLICE_BAD_RECORD);
+    else if (vmin_hi < kTwo39Hi) note_status(&status[s], AVR_SLICE_RETRY_SERIAL);   // the integer form walks it again, from the start
 }
 
 // Pass 1 for batches with no more slices than the chip has SIMDs: a WAVE per slice.  The walk is bound by its instruction
@@ -342,8 +353,8 @@ __device__ __forceinline__ void ranges_wave_body(uint32_t s, uint32_t long_chunk
     }
     const bool bad = __any((high & 0x8000u) != 0);
     if (lane == 0) {
-        if (bad) status[s] = AVR_SLICE_BAD_RECORD;
-        else if (vmin_hi < kTwo39Hi) status[s] = AVR_SLICE_RETRY_SERIAL;   // the integer form walks it again, from the start
+        if (bad) note_status(&status[s], AVR_SLICE_BAD_RECORD);
+        else if (vmin_hi < kTwo39Hi) note_status(&status[s], AVR_SLICE_RETRY_SERIAL);   // the integer form walks it again, from the start
     }
 }
 
@@ -418,7 +429,7 @@ __device__ __forceinline__ bool pick_chunk(const K2Plan &p, uint32_t i, uint32_t
     o->s = s; o->gc = gc; o->c = gc - p.chunk_base[s]; o->n = p.n_bins[s];
     o->last = gc + 1 == p.chunk_base[s + 1];
     const uint32_t end_pos = o->last ? fin_pos[s] : ck_pos[gc + 1];
-    if (uint64_t(end_pos) + kTail > p.out_off[s + 1] - p.out_off[s]) { status[s] = AVR_SLICE_OVERFLOW; return false; }
+    if (uint64_t(end_pos) + kTail > p.out_off[s + 1] - p.out_off[s]) { atomicCAS(&status[s], want, AVR_SLICE_OVERFLOW); return false; }
     return true;
 }
 
@@ -558,9 +569,11 @@ size_t k2p_workspace_bytes(size_t n_slices, uint32_t total_chunks, uint64_t out_
 namespace {
 constexpr uint32_t kMaxSegments = 8;
 struct Side { int dev; hipStream_t main, side; hipEvent_t seg[kMaxSegments], join; };
+std::vector<Side *> g_side_pool;
+std::mutex g_side_mu;
 hipError_t side_stream(hipStream_t s, Side **out) {
-    static std::vector<Side *> pool;
-    static std::mutex mu;
+    std::vector<Side *> &pool = g_side_pool;
+    std::mutex &mu = g_side_mu;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -577,6 +590,21 @@ hipError_t side_stream(hipStream_t s, Side **out) {
     return hipSuccess;
 }
 }  // namespace
+
+// The caller's stream is going away (avr_batch_destroy): what was kept for it -- the second stream and its events -- goes with it.
+void forget_side_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (size_t i = 0; i < g_side_pool.size();) {
+        Side *x = g_side_pool[i];
+        if (x->main != s) { i++; continue; }
+        (void)hipStreamSynchronize(x->side);
+        for (uint32_t k = 0; k < kMaxSegments; k++) (void)hipEventDestroy(x->seg[k]);
+        (void)hipEventDestroy(x->join);
+        (void)hipStreamDestroy(x->side);
+        delete x;
+        g_side_pool.erase(g_side_pool.begin() + long(i));
+    }
+}
 
 hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins, uint32_t n_slices,
                       const uint32_t *chunk_base, const uint32_t *chunk_slice, uint32_t total_chunks, uint64_t out_total,
@@ -617,8 +645,10 @@ hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
         else
             hipLaunchKernelGGL(k_k2p_ranges_fp, slice_grid, dim3(64), 0, s, p, n_slices, ck_range, ck_pos, fin_range, fin_pos, status, begin, end);
         if (side) {
-            if ((e = hipEventRecord(side->seg[k], s)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(s2, side->seg[k], 0)) != hipSuccess) return e;
+            if ((e = hipEventRecord(side->seg[k], s)) != hipSuccess || (e = hipStreamWaitEvent(s2, side->seg[k], 0)) != hipSuccess) {
+                (void)hipStreamSynchronize(s2);                  // the caller only knows its own stream: nothing of this call is left behind on the other
+                return e;
+            }
         }
         const dim3 grid = open ? chunk_grid : dim3(uint32_t((uint64_t(n_slices) * seg_len + 255) / 256));
         const uint32_t len = open ? 0 : seg_len;
@@ -626,8 +656,10 @@ hipError_t launch_k2p(hipStream_t s, const uint16_t *recs, const uint64_t *rec_o
         hipLaunchKernelGGL(k_k2p_code, grid, dim3(256), 0, s2, p, n_slices, total_chunks, ck_range, ck_pos, fin_pos, status, S, AVR_SLICE_OK, begin, len);
     }
     if (side) {
-        if ((e = hipEventRecord(side->join, s2)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(s, side->join, 0)) != hipSuccess) return e;
+        if ((e = hipEventRecord(side->join, s2)) != hipSuccess || (e = hipStreamWaitEvent(s, side->join, 0)) != hipSuccess) {
+            (void)hipStreamSynchronize(s2);
+            return e;
+        }
     }
     hipLaunchKernelGGL(k_k2p_finish, dim3(n_slices), dim3(64), 0, s, p, fin_range, fin_pos, S, out, out_len, status, AVR_SLICE_OK);
     // The slices the double-precision walk handed over (AVR_SLICE_RETRY_SERIAL: a range below 2^39 somewhere), start to end in the

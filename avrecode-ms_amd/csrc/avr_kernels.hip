@@ -811,10 +811,18 @@ __global__ __launch_bounds__(256) void k_expand_records8(const uint8_t *in, cons
 
 // The renumbering's scratch (4.25 KiB: used[32] + n_dense | table[1024] | index[1024]): one per (device, stream), made on
 // first use and kept -- work on one stream is ordered, so consecutive calls may share it, and no call allocates.
+// (One thread per stream: the census of a call and the kernel that reads its table are separate launches with a 4-byte wait between
+// them, so a second host thread enqueueing on the SAME stream in that window would overwrite the table -- as include/avrecode_ms_amd.h
+// says of every device-resident entry point, a stream is used by one thread at a time.)
+namespace {
+struct ScratchSlot { int dev; hipStream_t s; uint8_t *p; };
+std::vector<ScratchSlot> g_scratch;
+std::mutex g_scratch_mu;
+}  // namespace
 static hipError_t stream_scratch(hipStream_t s, uint8_t **out) {
-    struct Slot { int dev; hipStream_t s; uint8_t *p; };
-    static std::vector<Slot> slots;
-    static std::mutex mu;
+    using Slot = ScratchSlot;
+    std::vector<Slot> &slots = g_scratch;
+    std::mutex &mu = g_scratch_mu;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -826,6 +834,18 @@ static hipError_t stream_scratch(hipStream_t s, uint8_t **out) {
     slots.push_back(Slot{dev, s, p});
     *out = p;
     return hipSuccess;
+}
+
+void forget_side_stream(hipStream_t s);                          // avr_k2p.hip
+// A stream is about to be destroyed (avr_batch_destroy): the resources kept per (device, stream) go with it, so that a process that
+// makes and destroys batches (one per file, say) does not collect them.
+void forget_stream(hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        for (size_t i = 0; i < g_scratch.size();)
+            if (g_scratch[i].s == s) { (void)hipFree(g_scratch[i].p); g_scratch.erase(g_scratch.begin() + long(i)); } else i++;
+    }
+    forget_side_stream(s);
 }
 
 // The one-lane-per-slice kernel keeps 64 x (contexts) state bytes in LDS per wave, so it renumbers the batch onto the

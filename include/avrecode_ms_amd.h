@@ -204,6 +204,9 @@ int avr_multi_load(avr_multi *m, uint64_t *bins_per_device);
  * A caller that must not block uses the batch API (avr_batch_submit sizes the launches by the previous batch's count and
  * checks afterwards) or resolved codes (avr_cabac_encode_resolved_device / _codes_device and every K2 entry: no wait).
  * These are what the batch API is made of and what bench.py times with inputs already resident in HBM.
+ * ONE THREAD PER STREAM: the library keeps a few kilobytes of scratch (and, for the chunked K2, a second stream with its
+ * events) per (device, stream); a call's kernels find them there, so two host threads must not enqueue on the same stream
+ * at the same time.  What is kept for a batch's own stream is released by avr_batch_destroy.
  *
  * Slice-major layout: slice i's records are recs[rec_off[i] .. rec_off[i] + n_bins[i]);
  * rec_off[] entries are multiples of 8 records (16 bytes).
