@@ -225,6 +225,16 @@ _hooks_lib = None
 
 
 @contextlib.contextmanager
+def library_sha256() -> str:
+    """SHA-256 of the product library as it stands on disk (what profiles/pmc_traffic.json keys its counters by)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(LIB_PATH, "rb") as f:
+        for block in iter(lambda: f.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()
+
+
 def test_hooks(**hooks):
     """FOR tests/ ONLY.  Inside the block, lib() is libavrecode_hip_hooks.so -- the same sources built with
     -DAVR_TEST_HOOKS -- with the named hooks set (csrc/avr_internal.h: k1p_force_retry_every, census_stride,

@@ -27,8 +27,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 DEFAULT_SLICES = {2: 512, 3: 4096, 4: 16384, 5: 1 << 20}
-K1P_KERNELS = ("K1p: k_k1p_{census,densemap,local,ctxchain,replay,b2,c,d} + the idle serial fallback (one step = all of "
-               "them; largest: k_k1p_replay)")
+K1P_KERNELS = ("K1p: k_k1p_{census,densemap,local,chain_seg + chain_fix (up to 49 152 (slice, context) pairs, long slices: config 2) or "
+               "ctxchain (beyond: configs 3, 4),replay,b2,c,d} + the idle serial fallback (one step = all of them; largest: k_k1p_local "
+               "and k_k1p_replay, about equal)")
 WORKLOAD_NAME = {
     2: "config2: 1080p30 CABAC clip, 1 slice/frame, 512 frames (synthetic, 8160 macroblocks per slice)",
     3: "config3: 16 files x 256 slices, log-normal slice sizes (synthetic)",
@@ -408,8 +409,12 @@ def main():
         if os.path.exists(tpath) and not args.test_hook:
             try:
                 t = json.load(open(tpath)).get(f"{args.kind}_{path}_w{args.workload}_s{n_slices}", {})
-                traffic, traffic_cal = t.get("hbm_bytes_per_launch"), t.get("hbm_bytes_per_launch_calibrated")
-                traffic_source = "profiles/pmc_traffic.json" if traffic is not None else None
+                # the counters belong to the library they were collected on: a figure of another build is not this run's traffic
+                if t.get("library_sha256") == avr.library_sha256():
+                    traffic, traffic_cal = t.get("hbm_bytes_per_launch"), t.get("hbm_bytes_per_launch_calibrated")
+                    traffic_source = "profiles/pmc_traffic.json" if traffic is not None else None
+                elif t:
+                    traffic_source = "none: profiles/pmc_traffic.json holds this command's counters for another build of the library"
             except Exception:
                 traffic = None
         line = {

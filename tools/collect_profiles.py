@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn one tools/gpu_final_r3.sh run (gpurun_out/TAG/, parts a, b, c) into the committed summaries under profiles/:
+"""Turn one tools/gpu_final_r4.sh run (gpurun_out/TAG/, parts a, b, c) into the committed summaries under profiles/:
    python tools/collect_profiles.py TAG ROUND        e.g.  fin3 r03
 kernel-trace stats and the PMC counter files are copied as they are (kernels of this library only for
 the counters); pmc_traffic.json is what bench.py's roofline.traffic reads."""
@@ -48,7 +48,12 @@ def per_kernel(path, counter, steps_key="avr::"):
 
 LANE_CHUNK_READERS = ("k_k1p_local", "k_k1p_replay", "k_k1p_chain", "k_k1p_ctxchain", "k_k2p_code", "k_k2p_ranges", "k_cabac_encode", "k_range_encode")
 traffic = {}
+sys.path.insert(0, ROOT)
+import avrecode_ms_amd as _avr                                   # the library the counters were collected on (the tree is as it was pushed)
+LIB_SHA = _avr.library_sha256()
 for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches of one step"),
+                      (3, "cabac_chunked_w3_s4096", "K1p pipeline (config 3: 4 096 ragged slices), all launches of one step"),
+                      (4, "cabac_chunked_w4_s16384", "K1p pipeline (config 4: 16 384 slices), all launches of one step"),
                       (5, "cabac_serial_w5_s1048576", "k_k1_census + k_k1p_densemap + k_cabac_encode<tiled>: all launches of one step"),
                       ("5lds", "cabac_serial_w5_s1048576_test_hook_k1_emit_lds", "the same with the reference-form coder and the LDS-row emitter (test build, hook k1_emit_lds): a measured variant"),
                       ("5ref", "cabac_serial_w5_s1048576_test_hook_k1_form_ref", "the same with the coder as cabac_code.h writes it (test build, hook k1_form_ref): round 2's shipped form")):
@@ -67,7 +72,7 @@ for w, key, label in ((2, "cabac_chunked_w2_s512", "K1p pipeline, all launches o
     # profiles/r03_hbm_counter_calibration.txt: a lane that walks a chunk of its own reads 1.2 .. 1.5 x what FETCH_SIZE says, not 2 x
     fcal = sum(v * (1.5 if any(k.startswith(n) for n in LANE_CHUNK_READERS) else 2.0) for k, v in fetch.items())
     traffic[key] = {
-        "kernel": label, "FETCH_SIZE_KB_raw_sum": fsum, "WRITE_SIZE_KB_raw_sum": wsum,
+        "kernel": label, "library_sha256": LIB_SHA, "FETCH_SIZE_KB_raw_sum": fsum, "WRITE_SIZE_KB_raw_sum": wsum,
         "fetch_bytes_corrected_x2": fsum * 1024 * 2, "write_bytes": wsum * 1024,
         "hbm_bytes_per_launch": fsum * 1024 * 2 + wsum * 1024,
         "fetch_bytes_calibrated": fcal * 1024, "hbm_bytes_per_launch_calibrated": fcal * 1024 + wsum * 1024,
@@ -97,7 +102,7 @@ for d in ("w2k2", "w4k2"):                               # kernel stats of the c
 benches = sorted(os.path.basename(p)[len("bench_"):-len(".json")] for p in glob.glob(os.path.join(src, "bench_*.json")))
 for b in benches:
     shutil.copy(os.path.join(src, f"bench_{b}.json"), os.path.join(dst, f"{rnd}_bench_{b}.json"))
-for extra in ("cli_timing.txt",):
+for extra in ("cli_timing.txt", "ubench_issue_rate.txt", "ubench_lds_chain.txt", "ubench_read_patterns.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{rnd}_{extra}"))
 reh = os.path.join(ROOT, "gpurun_out", "rehearsal_2ranks_w4.json")
