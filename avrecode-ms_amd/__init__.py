@@ -224,7 +224,6 @@ def lib():
 _hooks_lib = None
 
 
-@contextlib.contextmanager
 def library_sha256() -> str:
     """SHA-256 of the product library as it stands on disk (what profiles/pmc_traffic.json keys its counters by)."""
     import hashlib
@@ -235,6 +234,7 @@ def library_sha256() -> str:
     return h.hexdigest()
 
 
+@contextlib.contextmanager
 def test_hooks(**hooks):
     """FOR tests/ ONLY.  Inside the block, lib() is libavrecode_hip_hooks.so -- the same sources built with
     -DAVR_TEST_HOOKS -- with the named hooks set (csrc/avr_internal.h: k1p_force_retry_every, census_stride,
