@@ -146,7 +146,7 @@ int main() {
     CK(hipMemset(buf, 1, kBytes + 4096));
     const uint64_t nch = kBytes / kChunk;
     timeit("stream, 16 B a lane", [&] { hipLaunchKernelGGL(k_stream, dim3(256 * 16), dim3(256), 0, 0, buf, out, kBytes / 16); });
-#define LC(LINE, WORK, BLK) timeit("lane-chunk, " #LINE " B a trip, work " #WORK ", workgroups of " #BLK, [&] { hipLaunchKernelGGL((k_lane_chunk<LINE, WORK>), dim3((nch + BLK - 1) / BLK), dim3(BLK), 0, 0, buf, out, nch); })
+#define LC(LINE, WORK, BLK) timeit("lane-chunk, " #LINE " B a trip, the next trip's loads inside a branch, work " #WORK ", workgroups of " #BLK, [&] { hipLaunchKernelGGL((k_lane_chunk<LINE, WORK>), dim3((nch + BLK - 1) / BLK), dim3(BLK), 0, 0, buf, out, nch); })
 #define TL(WORK, BLK) timeit("tile, 16 B a lane a trip, work " #WORK ", workgroups of " #BLK, [&] { hipLaunchKernelGGL((k_tile<WORK>), dim3((nch + BLK - 1) / BLK), dim3(BLK), 0, 0, buf, out, nch); })
     LC(64, 0, 256); LC(64, 8, 256); LC(64, 64, 256); LC(128, 8, 256); LC(32, 8, 256); LC(16, 8, 256);
     TL(0, 256); TL(8, 256); TL(64, 256);
@@ -158,6 +158,10 @@ int main() {
         snprintf(name, sizeof name, "tile, %d trips in flight, %u B a chunk, %u waves a CU (ms for 310 M records)", D, C16 * 16, waves); \
         if (timeit(name, [&] { hipLaunchKernelGGL((k_tile_deep<D>), dim3((nch + 255) / 256), dim3(256), lds, 0, buf, out, nch, C16); })) return 1; }
         TDEEP(1, 128) TDEEP(2, 128) TDEEP(4, 128) TDEEP(8, 128) TDEEP(1, 64) TDEEP(2, 64) TDEEP(4, 64) TDEEP(8, 64)
+#define DEEP(D) { CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lane_deep<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        snprintf(name, sizeof name, "lane-chunk, %d lines of 64 B in flight, loads unconditional (clamped), %u waves a CU", D, waves); \
+        if (timeit(name, [&] { hipLaunchKernelGGL((k_lane_deep<D>), dim3((nch + 255) / 256), dim3(256), lds, 0, buf, out, nch); })) return 1; }
+        DEEP(1) DEEP(2) DEEP(4)
     }
     CK(hipFree(buf)); CK(hipFree(out));
     return 0;
