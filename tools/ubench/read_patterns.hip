@@ -62,31 +62,31 @@ __global__ __launch_bounds__(1024) void k_tile(const uint4 *in, uint32_t *out, u
 }
 
 // D cache lines (64 B each) of the lane's chunk in flight, rolled loop: the ring of registers is rotated by hand
-template <int D>
+template <int D, int N = 4>      // N x 16 bytes a trip
 __global__ __launch_bounds__(1024) void k_lane_deep(const uint4 *in, uint32_t *out, uint64_t n_chunks) {
     extern __shared__ uint32_t dyn[];
     const uint64_t c = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
     if (c >= n_chunks) return;
     const uint4 *q = in + c * (kChunk / 16);
-    uint4 ring[D][4];
+    uint4 ring[D][N];
 #pragma unroll
     for (int d = 0; d < D; d++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) ring[d][j] = q[d * 4 + j];
+        for (int j = 0; j < N; j++) ring[d][j] = q[d * N + j];
     uint32_t acc = 0;
-    constexpr uint32_t trips = kChunk / 64;
+    constexpr uint32_t trips = kChunk / (16 * N);
 #pragma unroll 1
     for (uint32_t t = 0; t < trips; t += D) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            uint4 cur[4];
+            uint4 cur[N];
 #pragma unroll
-            for (int j = 0; j < 4; j++) cur[j] = ring[d][j];
+            for (int j = 0; j < N; j++) cur[j] = ring[d][j];
             const uint32_t nt = t + d + D < trips ? t + d + D : trips - 1;          // never a load inside a branch: the index is clamped instead
 #pragma unroll
-            for (int j = 0; j < 4; j++) ring[d][j] = q[nt * 4 + j];
+            for (int j = 0; j < N; j++) ring[d][j] = q[nt * N + j];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < N; j++) {
                 uint32_t x = cur[j].x ^ cur[j].y ^ cur[j].z ^ cur[j].w;
 #pragma unroll
                 for (int k = 0; k < 8; k++) x = __builtin_amdgcn_perm(x, acc, x) + k;
@@ -162,6 +162,12 @@ int main() {
         snprintf(name, sizeof name, "lane-chunk, %d lines of 64 B in flight, loads unconditional (clamped), %u waves a CU", D, waves); \
         if (timeit(name, [&] { hipLaunchKernelGGL((k_lane_deep<D>), dim3((nch + 255) / 256), dim3(256), lds, 0, buf, out, nch); })) return 1; }
         DEEP(1) DEEP(2) DEEP(4)
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lane_deep<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        snprintf(name, sizeof name, "lane-chunk, one line of 128 B in flight, loads unconditional, %u waves a CU", waves);
+        if (timeit(name, [&] { hipLaunchKernelGGL((k_lane_deep<1, 8>), dim3((nch + 255) / 256), dim3(256), lds, 0, buf, out, nch); })) return 1;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_lane_deep<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        snprintf(name, sizeof name, "lane-chunk, one half line of 32 B in flight, loads unconditional, %u waves a CU", waves);
+        if (timeit(name, [&] { hipLaunchKernelGGL((k_lane_deep<1, 2>), dim3((nch + 255) / 256), dim3(256), lds, 0, buf, out, nch); })) return 1;
     }
     CK(hipFree(buf)); CK(hipFree(out));
     return 0;
