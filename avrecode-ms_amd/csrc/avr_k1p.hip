@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
 // towards its own end, an LPS moves it back by transIdxLPS, which is non-decreasing in pStateIdx: cabac_code.h:43-47 with
 // ITU-T H.264 Table 9-45; tests/test_k1p_emul.py walks all pairs).  So when the walks from the two extreme states have met,
 // every state in between has met them too, and from there on the context's state does not depend on where the segment was
-// entered.  Each (slice, context) chain is cut into kChainSegs segments of equal chunk counts:
+// entered.  Each (slice, context) chain is cut into n_segs segments of equal chunk counts (how many: kChainWaveSlots below):
 //   k_k1p_chain_seg   lane per (slice, context, segment): both extreme states through the segment's chunks, side by side (two
 //                     independent look-up chains in flight); from the chunk where they have met, the state of every chunk is
 //                     noted in `est` as final.  Summary: exit state, the chunk they met at -- and, for the segments they do NOT
@@ -483,7 +483,12 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
 //                     between with more than kSegBits bins whose walks did not meet (nothing forbids it) is simply walked again,
 //                     chunk by chunk, by the lanes that need its exit state.
 // Batches of short slices (a segment would be a chunk or two) keep k_k1p_ctxchain, the start-to-end walk.
-constexpr uint32_t kChainSegs = 8, kSegWaves = 16;               // 16 waves share the 64 KiB look-up table: two such workgroups per CU
+constexpr uint32_t kMaxChainSegs = 16, kSegWaves = 16;           // 16 waves share the 64 KiB look-up table: two such workgroups per CU
+// How many segments (r4): as many as keep every wave of the launch resident at once -- the chip holds 8 192 of these waves (two workgroups
+// of 16 a CU), a launch takes as long as its longest lane's walk, and a second round of workgroups would double that.  Lanes are dealt
+// 64 (slice, context) pairs to a wave across slice boundaries (round 3 gave a slice's 86 contexts two waves of 43 lanes): 688 full waves a
+// segment for config 2 instead of 1 024, which is what lets its chains be cut in 11 instead of 8.
+constexpr uint32_t kChainWaveSlots = 8192;
 constexpr uint32_t kSegBits = 128;                               // bins a segment's bit string holds
 struct alignas(16) SegSummary {
     uint64_t bits[2];         // the segment's bins of this context, first bin in bit 0 of bits[0] (valid when n_bins <= kSegBits)
@@ -538,26 +543,26 @@ __device__ __forceinline__ void chain_step(const uint8_t *tn, const uint32_t *bw
 
 // Which (slice, context, segment) a lane of the two kernels below has; false: none.
 struct ChainLane { uint32_t s, k, seg, c_begin, c_end, nc, col; };
-__device__ __forceinline__ bool chain_lane(const Plan &p, uint32_t n_slices, uint32_t groups, uint32_t chain_lanes, const int32_t *status, ChainLane *o) {
-    const uint32_t wave = blockIdx.x * kSegWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint32_t seg = wave % kChainSegs, sg = wave / kChainSegs;
-    const uint32_t s = sg / groups, k = (sg - s * groups) + lane * groups, nk = p.n_states;
-    if (lane >= chain_lanes || s >= n_slices || status[s] != AVR_SLICE_OK || k >= nk) return false;
+__device__ __forceinline__ bool chain_lane(const Plan &p, uint32_t n_slices, uint32_t n_segs, const int32_t *status, ChainLane *o) {
+    const uint32_t wave = blockIdx.x * kSegWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63, nk = p.n_states;
+    const uint32_t seg = wave % n_segs, pair = (wave / n_segs) * 64 + lane;          // pair = slice * nk + context
+    const uint32_t s = pair / nk, k = pair - s * nk;
+    if (s >= n_slices || status[s] != AVR_SLICE_OK) return false;
     const uint32_t col = p.index[k];
     if (col >= p.ns_full) return false;
-    const uint32_t nc = (p.n_bins[s] + kChunk - 1) / kChunk, seg_len = (nc + kChainSegs - 1) / kChainSegs;
+    const uint32_t nc = (p.n_bins[s] + kChunk - 1) / kChunk, seg_len = (nc + n_segs - 1) / n_segs;
     const uint32_t c_begin = seg * seg_len < nc ? seg * seg_len : nc, c_end = c_begin + seg_len < nc ? c_begin + seg_len : nc;
     *o = ChainLane{s, k, seg, c_begin, c_end, nc, col};
     return true;
 }
 
-__global__ __launch_bounds__(64 * kSegWaves) void k_k1p_chain_seg(Plan p, uint32_t n_slices, uint32_t groups, uint32_t chain_lanes, const int32_t *status,
+__global__ __launch_bounds__(64 * kSegWaves) void k_k1p_chain_seg(Plan p, uint32_t n_slices, uint32_t n_segs, const int32_t *status,
                                                        const uint8_t *tng, const uint32_t *lbits, const uint16_t *lend, uint8_t *est, SegSummary *summ) {
     __shared__ uint8_t tn[kTnBytes];
     for (uint32_t i = threadIdx.x; i < kTnBytes / 16; i += 64 * kSegWaves) reinterpret_cast<uint4 *>(tn)[i] = reinterpret_cast<const uint4 *>(tng)[i];
     __syncthreads();
     ChainLane L;
-    if (!chain_lane(p, n_slices, groups, chain_lanes, status, &L)) return;
+    if (!chain_lane(p, n_slices, n_segs, status, &L)) return;
     const uint32_t nk = p.n_states, row4 = ((nk + 3) >> 2) << 2, k = L.k;
     const uint32_t c0 = p.chunk_base[L.s] + L.c_begin, n_ch = L.c_end - L.c_begin;
     const uint16_t *le = lend + size_t(c0) * nk + k;
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(64 * kSegWaves) void k_k1p_chain_seg(Plan p, uint32
     // which k_k1p_chain_fix answers by walking the whole segment again: slower for that pair, never wrong)
     o.bits[0] = bits0; o.bits[1] = bits1; o.n_bins = n_bins; o.exit_state = uint8_t(st[0]); o.met = st[0] == st[1] && met_chunk < 0xffffu;
     o.met_chunk = uint16_t(met_chunk < 0xffffu ? met_chunk : 0xffffu);
-    summ[(size_t(L.s) * nk + k) * kChainSegs + L.seg] = o;
+    summ[(size_t(L.s) * nk + k) * n_segs + L.seg] = o;
 }
 
 // A context's chain through chunks [c_first, c_first + n_ch) of its slice from state `st`, chunk by chunk (k_k1p_ctxchain's loop); NOTE: the
@@ -629,18 +634,18 @@ __device__ __forceinline__ uint32_t chain_chunks(const uint8_t *tn, const uint32
     return st[0];
 }
 
-__global__ __launch_bounds__(64 * kSegWaves) void k_k1p_chain_fix(Plan p, uint32_t n_slices, uint32_t groups, uint32_t chain_lanes, const int32_t *status,
+__global__ __launch_bounds__(64 * kSegWaves) void k_k1p_chain_fix(Plan p, uint32_t n_slices, uint32_t n_segs, const int32_t *status,
                                                        const uint8_t *tng, const uint32_t *lbits, const uint16_t *lend, const uint8_t *init_states,
                                                        uint8_t *est, const SegSummary *summ, uint8_t *final_states, uint32_t force_walk_every) {
     __shared__ uint8_t tn[kTnBytes];
     for (uint32_t i = threadIdx.x; i < kTnBytes / 16; i += 64 * kSegWaves) reinterpret_cast<uint4 *>(tn)[i] = reinterpret_cast<const uint4 *>(tng)[i];
     __syncthreads();
     ChainLane L;
-    if (!chain_lane(p, n_slices, groups, chain_lanes, status, &L)) return;
+    if (!chain_lane(p, n_slices, n_segs, status, &L)) return;
     const uint32_t nk = p.n_states, row4 = ((nk + 3) >> 2) << 2, k = L.k;
-    const SegSummary *mine = summ + (size_t(L.s) * nk + k) * kChainSegs;
+    const SegSummary *mine = summ + (size_t(L.s) * nk + k) * n_segs;
     const uint32_t init = init_states[size_t(L.s) * p.ns_full + L.col] & 127u;
-    const uint32_t c_slice = p.chunk_base[L.s], seg_len = (L.nc + kChainSegs - 1) / kChainSegs;
+    const uint32_t c_slice = p.chunk_base[L.s], seg_len = (L.nc + n_segs - 1) / n_segs;
     // test hook (always 0 in the product): for every n-th pair the summaries count for nothing -- every earlier segment is walked again
     const bool distrust = force_walk_every && (L.s * nk + k) % force_walk_every == 0;
     // The true entry state: back to the nearest segment whose walks met (or the slice's start), then forward through the ones between --
@@ -1339,7 +1344,7 @@ static inline ResolveLayout resolve_layout(size_t n_slices, uint32_t ns, const a
     L.est = take(uint64_t(pl->total_chunks) * ((ns + 3) / 4) * 4 + 16);
     L.stretch = take(uint64_t(pl->total_chunks) * sizeof(Stretch));
     L.meta = take(256 + 2048 + 2048 + kTnBytes);                 // used[32] + n_dense, table[1024], index[1024], tn
-    L.summ = take(uint64_t(n_slices) * ns * kChainSegs * sizeof(SegSummary));       // the segmented chains' summaries
+    L.summ = take(uint64_t(n_slices) * ns * kMaxChainSegs * sizeof(SegSummary));    // the segmented chains' summaries
     L.total = at;
     return L;
 }
@@ -1453,20 +1458,25 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
         if (const uint32_t v = test_hooks().chain_lanes) chain_lanes = v <= 64 ? v : 64;     // tuning switch (test build)
         const uint32_t groups = (n_states + chain_lanes - 1) / chain_lanes;
         const dim3 whole((n_slices * groups + kChainWaves - 1) / kChainWaves), block(64 * kChainWaves);
-        // Long slices: the chains in kChainSegs segments (walks from both extreme states, see k_k1p_chain_seg), then whatever pair
+        // Long slices: the chains in n_segs segments (walks from both extreme states, see k_k1p_chain_seg), then whatever pair
         // they could not settle start to end; short ones (a segment would be a chunk or two): start to end at once.
         // (what the segments buy is latency: eight times the lanes for an eighth of the dependent length.  Once a batch has lanes
         // enough to keep the LDS busy with table look-ups -- config 4: 16 384 slices x 86 contexts -- they only add look-ups: measured
         // 17.5 against 15.5 ms per step there, 0.277 against 0.289 ms for the chains of config 2's 512 slices, and the smaller the
         // batch the larger the gain: the chains do not get shorter with fewer slices, everything else does.)
         const bool few_lanes = uint64_t(n_slices) * n_states <= 49152;
-        if (uint64_t(pl->total_chunks) >= uint64_t(n_slices) * 4 * kChainSegs && !test_hooks().chain_whole && (few_lanes || test_hooks().chain_segments)) {
+        // segments: as many as keep the launch in one round of workgroups, at least four chunks each on average, at most kMaxChainSegs
+        const uint32_t pair_waves = uint32_t((uint64_t(n_slices) * n_states + 63) / 64);
+        uint32_t n_segs = kChainWaveSlots / pair_waves;
+        n_segs = n_segs > kMaxChainSegs ? kMaxChainSegs : n_segs;
+        const uint64_t by_length = uint64_t(pl->total_chunks) / (uint64_t(n_slices) * 4);
+        if (n_segs > by_length) n_segs = uint32_t(by_length);
+        if (const uint32_t v = test_hooks().chain_nsegs) n_segs = v < kMaxChainSegs ? v : kMaxChainSegs;
+        if (n_segs >= 2 && !test_hooks().chain_whole && (few_lanes || test_hooks().chain_segments)) {
             SegSummary *summ = reinterpret_cast<SegSummary *>(w + L.summ);
-            const uint32_t seg_lanes = 64;                       // eight times the waves of the start-to-end walk: full ones
-            const uint32_t seg_groups = (n_states + seg_lanes - 1) / seg_lanes;
-            const dim3 seg_grid((n_slices * seg_groups * kChainSegs + kSegWaves - 1) / kSegWaves), seg_block(64 * kSegWaves);
-            hipLaunchKernelGGL(k_k1p_chain_seg, seg_grid, seg_block, 0, s, p, n_slices, seg_groups, seg_lanes, status, tn, lbits, lend, est, summ);
-            hipLaunchKernelGGL(k_k1p_chain_fix, seg_grid, seg_block, 0, s, p, n_slices, seg_groups, seg_lanes, status, tn, lbits, lend, init_states, est, summ,
+            const dim3 seg_grid((pair_waves * n_segs + kSegWaves - 1) / kSegWaves), seg_block(64 * kSegWaves);
+            hipLaunchKernelGGL(k_k1p_chain_seg, seg_grid, seg_block, 0, s, p, n_slices, n_segs, status, tn, lbits, lend, est, summ);
+            hipLaunchKernelGGL(k_k1p_chain_fix, seg_grid, seg_block, 0, s, p, n_slices, n_segs, status, tn, lbits, lend, init_states, est, summ,
                                final_states, test_hooks().chain_force_redo);
         } else {
             hipLaunchKernelGGL(k_k1p_ctxchain, whole, block, 0, s, p, n_slices, groups, chain_lanes, status, tn, lbits, lend, init_states, est, final_states);
