@@ -387,8 +387,11 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
     const uint32_t wave = blockIdx.x * kChainWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     // group g of a slice takes contexts g, g + groups, g + 2 groups ...: neighbouring contexts (the hot ones of a
     // stream sit next to each other: the coefficient contexts of one block category) go to different waves
-    const uint32_t s = wave / groups, k = (wave - s * groups) + lane * groups, nk = p.n_states;
-    if (lane >= chain_lanes || s >= n_slices || status[s] != AVR_SLICE_OK || k >= nk) return;
+    // (groups == 0, r4: a batch with pairs enough for full waves -- 64 (slice, context) pairs to a wave across slice boundaries, no idle lanes:
+    // a stream of 86 contexts used to give every slice two waves of 43)
+    const uint32_t nk = p.n_states, pair = wave * 64 + lane;
+    const uint32_t s = groups ? wave / groups : pair / nk, k = groups ? (wave - s * groups) + lane * groups : pair - s * nk;
+    if ((groups && lane >= chain_lanes) || s >= n_slices || status[s] != AVR_SLICE_OK || k >= nk) return;
     const uint32_t col = p.index[k], row4 = ((nk + 3) >> 2) << 2;
     if (col >= p.ns_full) return;                                // a row beyond the batch's contexts (launch sized by a guess)
     uint32_t st = init_states[size_t(s) * p.ns_full + col] & 127u;
@@ -1456,8 +1459,10 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
         uint32_t chain_lanes = uint32_t((uint64_t(n_slices) * n_states + 2047) / 2048);
         chain_lanes = chain_lanes < kChainLanes ? kChainLanes : chain_lanes > 64 ? 64 : chain_lanes;
         if (const uint32_t v = test_hooks().chain_lanes) chain_lanes = v <= 64 ? v : 64;     // tuning switch (test build)
-        const uint32_t groups = (n_states + chain_lanes - 1) / chain_lanes;
-        const dim3 whole((n_slices * groups + kChainWaves - 1) / kChainWaves), block(64 * kChainWaves);
+        const bool packed = chain_lanes == 64;                   // lanes to spare: full waves of 64 pairs (see k_k1p_ctxchain)
+        const uint32_t groups = packed ? 0u : (n_states + chain_lanes - 1) / chain_lanes;
+        const uint32_t whole_waves = packed ? uint32_t((uint64_t(n_slices) * n_states + 63) / 64) : n_slices * groups;
+        const dim3 whole((whole_waves + kChainWaves - 1) / kChainWaves), block(64 * kChainWaves);
         // Long slices: the chains in n_segs segments (walks from both extreme states, see k_k1p_chain_seg), then whatever pair
         // they could not settle start to end; short ones (a segment would be a chunk or two): start to end at once.
         // (what the segments buy is latency: eight times the lanes for an eighth of the dependent length.  Once a batch has lanes
