@@ -55,6 +55,12 @@ struct ChunkSource {
         }
     }
     __device__ __forceinline__ uint4 load(uint32_t c) const { return p[size_t(c) * stride]; }
+    // the same read marked non-temporal: records are read once, and what they would push out of L2 are the output lines being filled
+    __device__ __forceinline__ uint4 load_nt(uint32_t c) const {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + size_t(c) * stride));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
 };
 
 // ------------------------------------------------------------------ K1
@@ -72,7 +78,8 @@ struct ChunkSource {
 //     starts in 134 reads 135 once any bin has gone through it.  That is where a context goes that the slice
 //     declares but the (sampled) census of the batch did not see -- the lane finds out at the end, at no cost
 //     per bin, and hands its slice back (AVR_SLICE_RETRY_SERIAL: coded by a second launch without renumbering).
-// Returns nothing; put_terminate(1) is found by the caller from the record value.
+//   * 131 / 133 remember put_terminate(1): the terminate context goes 130 -> 131 at the first one and 131 -> 133 at any terminate bin
+//     after it (both rows are no-ops); the caller reads the byte once, at the end of the slice (k_cabac_encode).
 struct CabacLane {
     CabacEncoder e;
 
@@ -132,6 +139,31 @@ struct CabacLaneN {
         sp += int32_t(sh);
         *spb = uint8_t(ent.z >> 24);                                             // cabac_code.h:43-47
     }
+    // Four bins with their four state bytes read TOGETHER, before the first is coded: a bin's state is then one LDS round trip (its
+    // table entry) behind the previous bin's instead of two.  A bin whose context one of the group's earlier bins has just moved
+    // takes that bin's successor state instead of the byte read (the latest wins; where the states live does not depend on them,
+    // so the comparisons are off the chain); the four writes follow in order.  Measured variant: k_cabac_encode FORM 4.
+    __device__ __forceinline__ void bin4(const uint32_t (&rec)[4], const uint32_t (&off)[4], const uint4 *tabn, uint8_t *st_lane) {
+        uint32_t s[4], next[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) s[j] = st_lane[off[j]];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t sj = s[j];
+#pragma unroll
+            for (int i = 0; i < j; i++) sj = off[j] == off[i] ? next[i] : sj;
+            asm volatile("" : "+v"(sj));
+            uint4 ent = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(tabn) + ((sj << 5) | ((rec[j] & 1u) << 4)));
+            asm volatile("" : "+v"(ent.x), "+v"(ent.y));
+            uint32_t v;
+            const uint32_t sh = k1p::step_range_c(k1p::CodeEntryC{ent.x, ent.y, ent.z, ent.w}, &R, &v);
+            L2 = (L2 + v) << sh;
+            sp += int32_t(sh);
+            next[j] = ent.z >> 24;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) st_lane[off[j]] = uint8_t(next[j]);
+    }
     // the table entry of (state or pseudo state s, bin): see k_cabac_encode for the pseudo states
     static __device__ uint4 norm_entry(uint32_t s, uint32_t bin) {
         uint32_t row, sym, next, byp = 0;
@@ -144,7 +176,7 @@ struct CabacLaneN {
             row = t == 2 ? 0x02020202u : 0u;                                     // terminate: LPS range 2, valMPS 0 (:59-61)
             sym = t == 2 ? bin : 0u;
             byp = t == 0;                                                        // bypass: the bin itself goes to low (:52-54)
-            next = t == 6 ? 135u : s;
+            next = t == 6 ? 135u : (t == 3 || t == 5) ? 133u : (t == 2 && bin) ? 131u : s;   // 131: put_terminate(1) has been; 133: and a terminate bin after it
         }
         const uint32_t k = byp ? bin : 2u * sym;
         return make_uint4(row, sym ? ~0u : 0u, k | next << 24, byp - 23u);
@@ -329,7 +361,7 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
     uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
     uint8_t *final_states, int32_t want_status) {
     extern __shared__ uint32_t lds[];                            // per wave: state dwords [(n_rows + 4 + 3) / 4][64]; FORM 2: then 16 x 64 staging slots per wave
-    constexpr bool NORM = FORM == 1 || FORM == 3;
+    constexpr bool NORM = FORM == 1 || FORM == 3 || FORM == 4;
     __shared__ uint2 tab[136];                                   // 128 states + pseudo-states 128..135
     __shared__ uint4 tabn[NORM ? 272 : 1];                       // the normalised form's: by (state, bin)
     __shared__ uint32_t sel_off[2048];                           // selector -> byte offset of its state in the lane's column (up to 256 rows of 256 bytes, + 3)
@@ -352,9 +384,9 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
     }
     for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x)
         tab[i] = make_uint2(d_tables.packed[i][0], d_tables.packed[i][1]);
-    if (threadIdx.x < 8) {                                       // 128: bypass, 130: terminate (LPS range 2), 132 / 134 / 135: no-op
-        const uint32_t t = threadIdx.x, ps = 128 + t, next = t == 6 ? 135u : ps;
-        tab[ps] = make_uint2(t == 2 ? 0x02020202u : 0u, (t == 0 ? 0x80000000u : t >= 4 ? 0x40000000u : 0u) | next | next << 8);
+    if (threadIdx.x < 8) {                                       // 128: bypass, 130: terminate (LPS range 2), 131 / 133: after put_terminate(1), 132 / 134 / 135: no-op
+        const uint32_t t = threadIdx.x, ps = 128 + t, next = t == 6 ? 135u : (t == 3 || t == 5) ? 133u : ps, lps = t == 2 ? 131u : next;
+        tab[ps] = make_uint2(t == 2 ? 0x02020202u : 0u, (t == 0 ? 0x80000000u : t >= 3 ? 0x40000000u : 0u) | next | lps << 8);
     }
     if constexpr (NORM)
         for (uint32_t i = threadIdx.x; i < 272; i += blockDim.x) tabn[i] = CabacLaneN::norm_entry(i >> 1, i & 1u);
@@ -370,30 +402,39 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
     if (active) st = AVR_SLICE_OK;
     const uint32_t nb = active ? n_bins[slice] : 0;
 
-    // states: global (n_states bytes per slice, caller's numbering) -> LDS column of this lane
+    // states: global (n_states bytes per slice, caller's numbering) -> the LDS columns of the wave's lanes.  The wave takes its 64
+    // slices one after the other, lane k fetching the slice's state of row k (r4: 64 independent loads of one slice's row each; the
+    // lanes used to gather their own columns, row by row -- one load per row with 64 lines in it, each behind a load of index[k]).
     {
-        const uint8_t *src = init_states + size_t(slice) * n_states;
-        for (uint32_t k4 = 0; k4 < rows4; k4++) {
+        for (uint32_t k4 = 0; k4 < rows4; k4++) {                // the pseudo contexts (and padding); the contexts' own bytes follow
             uint32_t v = 0;
             for (uint32_t b = 0; b < 4; b++) {
                 const uint32_t k = 4 * k4 + b;
-                uint32_t sv = k == n_rows ? 128u : k == n_rows + 1 ? 130u : k == n_rows + 3 ? 134u : 132u;   // the pseudo contexts (and padding)
-                if (k < n_rows && active) {
-                    const uint32_t col = index ? uint32_t(index[k]) : k;        // 0xffff: a row beyond the batch's contexts (launch sized by a guess)
-                    sv = col < n_states ? src[col] : 0u;
-                }
+                const uint32_t sv = k < n_rows ? 0u : k == n_rows ? 128u : k == n_rows + 1 ? 130u : k == n_rows + 3 ? 134u : 132u;
                 v |= sv << (8 * b);
             }
             st32[k4 * 64 + lane] = v;
         }
+        uint8_t *st_wave = reinterpret_cast<uint8_t *>(st32);
+        const uint64_t act = __ballot(active);
+        for (uint32_t k0 = 0; k0 < n_rows; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t col = k < n_rows ? (index ? uint32_t(index[k]) : k) : 0xffffu;   // 0xffff: a row beyond the batch's contexts (launch sized by a guess)
+            uint8_t *dst = st_wave + ((k >> 2) << 8) + (k & 3);
+#pragma unroll 8
+            for (uint32_t j = 0; j < 64; j++) {
+                const uint32_t sj = __shfl(slice, j);
+                if (((act >> j) & 1u) && col < n_states) dst[j * 4] = init_states[size_t(sj) * n_states + col];
+            }
+        }
     }
     __syncthreads();
 
-    typename std::conditional<FORM == 3, CabacLaneNS, typename std::conditional<FORM == 1, CabacLaneN,
+    typename std::conditional<FORM == 3, CabacLaneNS, typename std::conditional<FORM == 1 || FORM == 4, CabacLaneN,
         typename std::conditional<FORM == 2, CabacLaneS, CabacLane>::type>::type>::type L;
     const uint64_t o0 = in_range ? out_off[slice] : 0;
     const uint32_t cap = in_range ? uint32_t(out_off[slice + 1] - o0) : 0;
-    if constexpr (FORM == 1) L.init(out + o0, cap);
+    if constexpr (FORM == 1 || FORM == 4) L.init(out + o0, cap);
     else if constexpr (FORM == 2 || FORM == 3) L.init(out + o0, cap, lds + (blockDim.x >> 6) * rows4 * 64 + wv * 1024 + lane);
     else L.e.init(0x7F800000u, out + o0, cap);                   // cabac_code.h:30
 
@@ -404,36 +445,54 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
     // inside a branch is waited for before the branch ends -- the "two chunks ahead" of rounds 1-3 waited out a memory latency per
     // eight bins (the same in k_range_encode since round 2; tools/ubench/read_patterns)
     const uint32_t last_chunk = n_chunks ? n_chunks - 1 : 0;
-    uint4 cur = nop4, nx1 = nop4;
-    if (n_chunks) { cur = src.load(0); nx1 = src.load(min(1u, last_chunk)); }
-    // put_terminate(1) (cabac_code.h:63-65) ends the slice: in a well-formed stream it is the last record,
-    // and what follows it in its 16-byte chunk is padding that changes nothing, so the bins are not
-    // tested one by one for it -- its position is only remembered (a bin after it flags the slice).
-    uint32_t term_at = 0xffffffffu;                              // record index of the first put_terminate(1)
-    constexpr uint32_t kTerm1 = (AVR_SEL_TERMINATE << 1) | 1;
-    for (uint32_t c = 0; c < n_chunks && term_at == 0xffffffffu; c++) {
-        const uint4 nx2 = src.load(min(c + 2, last_chunk));
-        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+    // put_terminate(1) (cabac_code.h:63-65) ends the slice: in a well-formed stream it is the last record, and what follows it in its
+    // 16-byte chunk is padding that changes nothing.  No bin is tested for it (r4; rounds 1-3 compared every record with it, three
+    // instructions a bin): the terminate pseudo context's state remembers -- 130 -> 131 at the first put_terminate(1), 131 -> 133 at
+    // any terminate bin after it -- and the lane looks at that byte and at its last record once, at the end.
+    auto code8 = [&](const uint4 &v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t offs[8];                                        // where the eight bins' states live: independent of the states, read ahead
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) offs[k] = sel_off[((w[k >> 1] >> ((k & 1) * 16)) >> 1) & 0x7ffu];
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t rec = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+            if constexpr (FORM == 4) {
+                if ((k & 3) == 0) {
+                    const uint32_t r4[4] = {w[k >> 1] & 0xffffu, w[k >> 1] >> 16, w[(k >> 1) + 1] & 0xffffu, w[(k >> 1) + 1] >> 16};
+                    const uint32_t o4[4] = {offs[k], offs[k + 1], offs[k + 2], offs[k + 3]};
+                    L.bin4(r4, o4, tabn, st_lane);
+                }
+            } else
             if constexpr (NORM) L.bin(rec, offs[k], tabn, st_lane);
             else L.bin(rec, offs[k], tab, st_lane);
             if constexpr (NORM) { if ((k & 3) == 3) L.digits(); }
             if constexpr (FORM == 2 || FORM == 3) { if (k == 7) L.rows(); }
-            const uint32_t t0 = rec == kTerm1 ? c * 8 + k : 0xffffffffu;
-            term_at = term_at < t0 ? term_at : t0;
         }
-        cur = nx1;
-        nx1 = nx2;
+    };
+    // The records come two chunks ahead, marked non-temporal (read once: nothing of them need stay in L2).
+    uint4 ca = nop4, cb = nop4;
+    if (n_chunks) { ca = src.load_nt(0); cb = src.load_nt(min(1u, last_chunk)); }
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        const uint4 nx2 = src.load_nt(min(c + 2, last_chunk));
+        code8(ca);
+        ca = cb;
+        cb = nx2;
+    }
+    constexpr uint32_t kTerm1 = (AVR_SEL_TERMINATE << 1) | 1;
+    bool after_finish = false;                                   // a bin after the put_terminate(1), which was finish()
+    if (active && nb) {
+        const uint32_t tstate = st_lane[(((n_rows + 1) >> 2) << 8) + ((n_rows + 1) & 3)];
+        if (tstate != 130u) {
+            const uint4 v = src.load(last_chunk);
+            const uint32_t i = (nb - 1) & 7u, d = i < 2 ? v.x : i < 4 ? v.y : i < 6 ? v.z : v.w;
+            after_finish = tstate != 131u || ((d >> ((i & 1u) * 16)) & 0xffffu) != kTerm1;
+        }
     }
     if (in_range) {
         if (active) {
             const bool missed = st_lane[(((n_rows + 3) >> 2) << 8) + ((n_rows + 3) & 3)] == 135u;
-            if (term_at != 0xffffffffu && term_at + 1 < nb) st = AVR_SLICE_BAD_RECORD;   // a bin after finish()
+            if (after_finish) st = AVR_SLICE_BAD_RECORD;
             else if constexpr (FORM != 0) L.finish();
             else L.e.finish();                                   // cabac_code.h:63-65 / ~encoder(), arithmetic_code.h:100
             L.e.w.flush();
@@ -442,12 +501,18 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
         }
         if (active) { out_len[slice] = L.e.w.n; status[slice] = st; }
         else if (want_status == AVR_SLICE_OK) out_len[slice] = 0;
-        if (final_states && active && st != AVR_SLICE_RETRY_SERIAL) {                            // final_states starts out as a copy of init_states when a renumbering is in use
-            uint8_t *dst = final_states + size_t(slice) * n_states;
-            const uint8_t *col = reinterpret_cast<const uint8_t *>(st32) + lane * 4;
-            for (uint32_t k = 0; k < n_rows; k++) {
-                const uint32_t c = index ? uint32_t(index[k]) : k;
-                if (c < n_states) dst[c] = col[((k >> 2) << 8) + (k & 3)];
+    }
+    if (final_states) {                                          // (final_states starts out as a copy of init_states when a renumbering is in use)
+        const uint64_t done = __ballot(in_range && active && st != AVR_SLICE_RETRY_SERIAL);
+        const uint8_t *st_wave = reinterpret_cast<const uint8_t *>(st32);
+        for (uint32_t k0 = 0; k0 < n_rows; k0 += 64) {           // slice by slice, lane k the state of row k: see the way in
+            const uint32_t k = k0 + lane;
+            const uint32_t col = k < n_rows ? (index ? uint32_t(index[k]) : k) : 0xffffu;
+            const uint8_t *from = st_wave + ((k >> 2) << 8) + (k & 3);
+#pragma unroll 8
+            for (uint32_t j = 0; j < 64; j++) {
+                const uint32_t sj = __shfl(slice, j);
+                if (((done >> j) & 1u) && col < n_states) final_states[size_t(sj) * n_states + col] = from[j * 4];
             }
         }
     }
@@ -903,9 +968,9 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
         // since round 3's table entries (avr_k1p.h, CodeEntryC) 31 VALU instructions a bin against the 48 of the form that reads
         // like cabac_code.h, and 2.44 against 2.55 ms per step on config 5.  Test hooks: k1_form_ref = that form (CabacLane),
         // k1_emit_lds = 1: it with the digits staged in LDS (CabacLaneS), 2: the shipped form with them (CabacLaneNS); same bytes all.
-        const int form = test_hooks().k1_emit_lds ? (test_hooks().k1_emit_lds == 2 ? 3 : 2) : test_hooks().k1_form_ref ? 0 : 1;
-        auto kern = tiled ? (form == 1 ? k_cabac_encode<true, 1> : form == 2 ? k_cabac_encode<true, 2> : form == 3 ? k_cabac_encode<true, 3> : k_cabac_encode<true, 0>)
-                          : (form == 1 ? k_cabac_encode<false, 1> : form == 2 ? k_cabac_encode<false, 2> : form == 3 ? k_cabac_encode<false, 3> : k_cabac_encode<false, 0>);
+        const int form = test_hooks().k1_emit_lds ? (test_hooks().k1_emit_lds == 2 ? 3 : 2) : test_hooks().k1_form_ref ? 0 : test_hooks().k1_fwd ? 4 : 1;
+        auto kern = tiled ? (form == 4 ? k_cabac_encode<true, 4> : form == 1 ? k_cabac_encode<true, 1> : form == 2 ? k_cabac_encode<true, 2> : form == 3 ? k_cabac_encode<true, 3> : k_cabac_encode<true, 0>)
+                          : (form == 4 ? k_cabac_encode<false, 4> : form == 1 ? k_cabac_encode<false, 1> : form == 2 ? k_cabac_encode<false, 2> : form == 3 ? k_cabac_encode<false, 3> : k_cabac_encode<false, 0>);
         if (lds > 48 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
             if (e != hipSuccess) return e;

@@ -69,7 +69,7 @@ def test_range_golden_vectors(avr):
 
 # ------------------------------------------------------------------ random, ragged, edge cases
 
-@pytest.mark.parametrize("form", ["ref", "norm", "lds", "ref-lds"])
+@pytest.mark.parametrize("form", ["ref", "norm", "lds", "ref-lds", "fwd"])
 @pytest.mark.parametrize("n_states", [4, 64, 460, 1024])
 def test_cabac_random_ragged(avr, oracle, n_states, form, hooks):
     """form: the one-lane-per-slice coder in normalised form with the digits taken every fourth bin in step across the wave
@@ -78,6 +78,8 @@ def test_cabac_random_ragged(avr, oracle, n_states, form, hooks):
         hooks(k1_form_ref=1)
     elif form == "lds":                                      # digits staged in LDS, 16-byte rows found by ballot: the north star's emitter on the shipped form (CabacLaneNS)
         hooks(k1_emit_lds=2)
+    elif form == "fwd":                                      # four state bytes read ahead, an earlier bin of the group forwarding its successor (CabacLaneN::bin4: a measured variant)
+        hooks(k1_fwd=1)
     elif form == "ref-lds":                                  # ... and on the form as the reference writes it (CabacLaneS)
         hooks(k1_emit_lds=1)
     rng = np.random.default_rng(100 + n_states)
