@@ -390,13 +390,22 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
     }
     if constexpr (NORM)
         for (uint32_t i = threadIdx.x; i < 272; i += blockDim.x) tabn[i] = CabacLaneN::norm_entry(i >> 1, i & 1u);
-    for (uint32_t sel = threadIdx.x; sel < 2048; sel += blockDim.x) {
-        uint32_t k;
-        if (sel < 1024) {                                        // a context of the slice that has no row: the census missed it
-            const uint32_t d = table ? uint32_t(table[sel]) : (sel < n_states ? sel : 0xffffu);
-            k = d < n_rows ? d : sel < n_states ? n_rows + 3 : n_rows + 2;
-        } else k = sel == AVR_SEL_BYPASS ? n_rows : sel == AVR_SEL_TERMINATE ? n_rows + 1 : n_rows + 2;
-        sel_off[sel] = ((k >> 2) << 8) + (k & 3);
+    for (uint32_t base = threadIdx.x; base < 2048; base += 8 * blockDim.x) {     // (eight entries a trip: their loads in flight together)
+        uint32_t dense[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t sel = base + u * blockDim.x;
+            dense[u] = table ? uint32_t(table[sel & 1023u]) : (sel < n_states ? sel : 0xffffu);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t sel = base + u * blockDim.x;
+            if (sel >= 2048) break;
+            uint32_t k;
+            if (sel < 1024) k = dense[u] < n_rows ? dense[u] : sel < n_states ? n_rows + 3 : n_rows + 2;   // n_rows + 3: a context of the slice that has no row: the census missed it
+            else k = sel == AVR_SEL_BYPASS ? n_rows : sel == AVR_SEL_TERMINATE ? n_rows + 1 : n_rows + 2;
+            sel_off[sel] = ((k >> 2) << 8) + (k & 3);
+        }
     }
 
     if (active) st = AVR_SLICE_OK;
@@ -421,10 +430,17 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
             const uint32_t k = k0 + lane;
             const uint32_t col = k < n_rows ? (index ? uint32_t(index[k]) : k) : 0xffffu;   // 0xffff: a row beyond the batch's contexts (launch sized by a guess)
             uint8_t *dst = st_wave + ((k >> 2) << 8) + (k & 3);
-#pragma unroll 8
-            for (uint32_t j = 0; j < 64; j++) {
-                const uint32_t sj = __shfl(slice, j);
-                if (((act >> j) & 1u) && col < n_states) dst[j * 4] = init_states[size_t(sj) * n_states + col];
+            const uint32_t colc = col < n_states ? col : 0u;     // (every load is made, sixteen in flight: a lane without a slice has slice 0)
+            for (uint32_t j0 = 0; j0 < 64; j0 += 16) {
+                uint8_t v[16];
+#pragma unroll
+                for (uint32_t u = 0; u < 16; u++) {              // (the slice's row is a scalar address, the lane's column the offset)
+                    const uint8_t *row = init_states + size_t(uint32_t(__builtin_amdgcn_readlane(int(slice), int(j0 + u)))) * n_states;
+                    v[u] = row[colc];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 16; u++)
+                    if (((act >> (j0 + u)) & 1u) && col < n_states) dst[(j0 + u) * 4] = v[u];
             }
         }
     }
@@ -511,8 +527,8 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
             const uint8_t *from = st_wave + ((k >> 2) << 8) + (k & 3);
 #pragma unroll 8
             for (uint32_t j = 0; j < 64; j++) {
-                const uint32_t sj = __shfl(slice, j);
-                if (((done >> j) & 1u) && col < n_states) final_states[size_t(sj) * n_states + col] = from[j * 4];
+                uint8_t *row = final_states + size_t(uint32_t(__builtin_amdgcn_readlane(int(slice), int(j)))) * n_states;
+                if (((done >> j) & 1u) && col < n_states) row[col] = from[j * 4];
             }
         }
     }
