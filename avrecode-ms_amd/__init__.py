@@ -161,6 +161,15 @@ SIGNATURES = {
     "avr_cabac_encode_chunked_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                                 c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_void_p]),
+    "avr_cabac_encode_chunked_device_hinted": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
+                                                       c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                       c_void_p, c_uint32, c_void_p]),
+    "avr_cabac_encode_chunked_second_pass_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
+                                                            c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                            c_void_p]),
+    "avr_cabac_encode_tiles_device_hinted": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                                     c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_uint32, c_void_p]),
     "avr_range_chunked_workspace_bytes": (c_size_t, [c_size_t, c_void_p, ctypes.c_uint64]),
     "avr_range_encode_chunked_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,
                                                 c_void_p, c_void_p, ctypes.c_uint64, c_void_p, c_void_p]),

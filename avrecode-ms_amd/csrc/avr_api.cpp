@@ -879,6 +879,60 @@ int avr_cabac_encode_chunked_device(int device, void *stream, const uint16_t *re
     return AVR_OK;
 }
 
+static int check_chunked(const uint64_t *rec_off, const uint32_t *n_bins, const uint64_t *out_off, size_t n_slices, size_t n_states,
+                         const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes, const int32_t *status) {
+    if (int rc = check_common(rec_off, n_bins, out_off, n_slices)) return rc;
+    if (n_states > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "n_states %zu > %d", n_states, AVR_MAX_STATES);
+    if (!plan || (n_slices && (!plan->res_off || !plan->chunk_base || !plan->chunk_slice || !plan->blk_base || !plan->blk_slice ||
+                               !plan->dig_off || !workspace || !status)))
+        return fail(AVR_ERR_INVALID, "null plan pointer");
+    if (workspace_bytes < avr::k1p_workspace_bytes(n_slices, uint32_t(n_states), plan))
+        return fail(AVR_ERR_CAPACITY, "workspace of %zu bytes is smaller than avr_cabac_chunked_workspace_bytes()", workspace_bytes);
+    return AVR_OK;
+}
+
+int avr_cabac_encode_chunked_device_hinted(int device, void *stream, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                                           size_t n_slices, const uint8_t *init_states, size_t n_states, const avr_chunk_plan *plan,
+                                           void *workspace, size_t workspace_bytes, uint8_t *out, const uint64_t *out_off,
+                                           uint32_t *out_len, int32_t *status, uint8_t *final_states, uint32_t rows_hint, uint32_t *counts) {
+    if (!counts) return fail(AVR_ERR_INVALID, "null counts");
+    if (int rc = check_chunked(rec_off, n_bins, out_off, n_slices, n_states, plan, workspace, workspace_bytes, status)) return rc;
+    if (int rc = select_device(device)) return rc;
+    counts[0] = counts[1] = 0;
+    if (n_slices == 0) return AVR_OK;
+    const avr::DenseHint hint{std::min<uint32_t>(rows_hint, uint32_t(n_states)), counts, counts + 1};
+    AVR_HIP(avr::launch_k1p(static_cast<hipStream_t>(stream), recs, rec_off, n_bins, uint32_t(n_slices), init_states,
+                            uint32_t(n_states), plan, workspace, out, out_off, out_len, status, final_states, &hint));
+    return AVR_OK;
+}
+
+int avr_cabac_encode_chunked_second_pass_device(int device, void *stream, const uint16_t *recs, const uint64_t *rec_off, const uint32_t *n_bins,
+                                                size_t n_slices, const uint8_t *init_states, size_t n_states, const avr_chunk_plan *plan,
+                                                void *workspace, size_t workspace_bytes, uint8_t *out, const uint64_t *out_off,
+                                                uint32_t *out_len, int32_t *status, uint8_t *final_states) {
+    if (int rc = check_chunked(rec_off, n_bins, out_off, n_slices, n_states, plan, workspace, workspace_bytes, status)) return rc;
+    if (int rc = select_device(device)) return rc;
+    if (n_slices == 0) return AVR_OK;
+    AVR_HIP(avr::launch_k1p_retry(static_cast<hipStream_t>(stream), recs, rec_off, n_bins, uint32_t(n_slices), init_states,
+                                  uint32_t(n_states), plan, workspace, out, out_off, out_len, status, final_states));
+    return AVR_OK;
+}
+
+int avr_cabac_encode_tiles_device_hinted(int device, void *stream, const void *tiles, const uint64_t *tile_off, const uint32_t *n_bins,
+                                         const uint32_t *order, size_t n_slices, const uint8_t *init_states, size_t n_states,
+                                         uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status, uint8_t *final_states,
+                                         uint32_t rows_hint, uint32_t *counts) {
+    if (!counts) return fail(AVR_ERR_INVALID, "null counts");
+    if (int rc = check_common(tile_off, n_bins, out_off, n_slices)) return rc;
+    if (n_states > AVR_MAX_STATES) return fail(AVR_ERR_INVALID, "n_states %zu > %d", n_states, AVR_MAX_STATES);
+    if (int rc = select_device(device)) return rc;
+    counts[0] = counts[1] = 0;
+    const avr::DenseHint hint{std::min<uint32_t>(rows_hint, uint32_t(n_states)), counts, nullptr};
+    AVR_HIP(avr::launch_cabac_encode(true, static_cast<hipStream_t>(stream), tiles, tile_off, n_bins, order, uint32_t(n_slices),
+                                     init_states, uint32_t(n_states), out, out_off, out_len, status, final_states, AVR_SLICE_OK, true, &hint));
+    return AVR_OK;
+}
+
 size_t avr_range_chunked_workspace_bytes(size_t n_slices, const avr_chunk_plan *plan, uint64_t out_total) {
     if (!plan) return 0;
     return avr::k2p_workspace_bytes(n_slices, plan->total_chunks, out_total);

@@ -75,6 +75,10 @@ class DeviceWorkload:
         self.final_states = (torch.empty(self.n_slices * max(n_states, 1), dtype=torch.uint8, device=dev)
                              if kind == KIND_CABAC else None)
         self.total_bins = int(n_bins.to(torch.int64).sum().item())
+        # K1 sized by the context count of the previous run of this object (avr_cabac_encode_*_device_hinted): no host round trip
+        # in the call; settle() looks at what the device reported once the caller has synchronised
+        self.rows_hint, self._hinted_path = 0, None
+        self._counts = torch.zeros(2, dtype=torch.int32).pin_memory() if dev.type == "cuda" and kind == KIND_CABAC else None
 
     @classmethod
     def synth(cls, workload, n_slices, kind=KIND_CABAC, device_index=0, scale_permille=1000, first_slice=0):
@@ -136,9 +140,51 @@ class DeviceWorkload:
         return w
 
     def encode(self):
-        """One pass of the hot path over the batch (enqueued on torch's current stream)."""
+        """One pass of the hot path over the batch (enqueued on torch's current stream).  K1: sized by the context count the previous
+        run of this object reported (none yet: the call asks the device and waits); exact whatever the guess.  settle() after a
+        synchronisation takes the count over for the next run."""
+        if self.kind == KIND_CABAC and self._counts is not None:
+            import torch
+            self._hinted_path = "tiles"
+            _check(lib().avr_cabac_encode_tiles_device_hinted(
+                self.device_index, _stream_ptr(torch), self.tiles.data_ptr(), self.tile_off.data_ptr(), self.n_bins.data_ptr(),
+                self.order.data_ptr(), self.n_slices, self.init_states.data_ptr() if self.init_states is not None else None, self.n_states,
+                self.out.data_ptr(), self.out_off.data_ptr(), self.out_len.data_ptr(), self.status.data_ptr(),
+                self.final_states.data_ptr() if self.final_states is not None else None, self.rows_hint, self._counts.data_ptr()))
+            return
         encode_tiles(self.kind, self.tiles, self.tile_off, self.n_bins, self.order, self.out, self.out_off,
                      self.out_len, self.status, self.init_states, self.n_states, self.final_states, self.device_index)
+
+    def settle(self):
+        """After the caller has synchronised the stream of encode() / encode_chunked(): what the device reported about the run that
+        was sized by a guess.  Returns {"rows": context rows the batch needs, "hint": what the run was sized by, "redone": ...}.
+        The one-lane-per-slice path is exact whatever the guess; the chunked path is run again (asking the device) if the batch needed
+        more rows than guessed, and its second pass is run if slices were left for it -- then the stream is synchronised again."""
+        import torch
+        if self._counts is None or self._hinted_path is None:
+            return {"rows": 0, "hint": 0, "redone": False}
+        rows, left, used = int(self._counts[0]), int(self._counts[1]), self.rows_hint
+        redone = False
+        if self._hinted_path == "chunked" and used and rows > used:
+            self.status.copy_(self._status_before)
+            self.rows_hint = 0
+            self.encode_chunked()
+            torch.cuda.synchronize(self.n_bins.device)
+            rows, left, redone = int(self._counts[0]), int(self._counts[1]), True
+        if self._hinted_path == "chunked" and left:
+            recs, rec_off = self._slice_major()
+            p = self._chunk_plan()
+            ws_ptr = (p["ws"].data_ptr() + 255) // 256 * 256
+            _check(lib().avr_cabac_encode_chunked_second_pass_device(
+                self.device_index, _stream_ptr(torch), recs.data_ptr(), rec_off.data_ptr(), self.n_bins.data_ptr(),
+                self.n_slices, self.init_states.data_ptr(), self.n_states, ctypes.byref(p["plan"]), ws_ptr, p["ws_bytes"],
+                self.out.data_ptr(), self.out_off.data_ptr(), self.out_len.data_ptr(), self.status.data_ptr(),
+                self.final_states.data_ptr() if self.final_states is not None else None))
+            torch.cuda.synchronize(self.n_bins.device)
+            redone = True
+        if rows:
+            self.rows_hint = min(self.n_states, rows + 8)        # a little room, as avr_batch leaves (csrc/avr_api.cpp)
+        return {"rows": rows, "hint": used, "redone": redone}
 
     def densify(self):
         """Renumber the batch onto the contexts it uses (fewer state bytes in LDS -> more waves per CU).
@@ -258,6 +304,16 @@ class DeviceWorkload:
                 self.out_len.data_ptr(), self.status.data_ptr()))
             return
         ws_ptr = (p["ws"].data_ptr() + 255) // 256 * 256
+        if self._counts is not None:                         # sized by the previous run's context count: see encode(), settle()
+            self._hinted_path = "chunked"
+            if getattr(self, "_status_before", None) is None:
+                self._status_before = self.status.clone()    # (a run whose guess was too small is repeated from these)
+            _check(lib().avr_cabac_encode_chunked_device_hinted(
+                self.device_index, _stream_ptr(torch), recs.data_ptr(), rec_off.data_ptr(), self.n_bins.data_ptr(),
+                self.n_slices, self.init_states.data_ptr(), self.n_states, ctypes.byref(p["plan"]), ws_ptr, p["ws_bytes"],
+                self.out.data_ptr(), self.out_off.data_ptr(), self.out_len.data_ptr(), self.status.data_ptr(),
+                self.final_states.data_ptr() if self.final_states is not None else None, self.rows_hint, self._counts.data_ptr()))
+            return
         _check(lib().avr_cabac_encode_chunked_device(
             self.device_index, _stream_ptr(torch), recs.data_ptr(), rec_off.data_ptr(), self.n_bins.data_ptr(),
             self.n_slices, self.init_states.data_ptr(), self.n_states, ctypes.byref(p["plan"]), ws_ptr, p["ws_bytes"],

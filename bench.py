@@ -375,8 +375,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    # K1 is sized by the context count the previous run of the workload reported (avr_cabac_encode_*_device_hinted, the way avr_batch
+    # runs from its second batch on): the first warm-up step asks the device and waits, the steps after it wait for nothing; the
+    # count every timed step reported is looked at after the timed region (settle) and a guess that was too small fails the line.
+    settle = getattr(w, "settle", None) if kind == avr.KIND_CABAC and args.records != "resolved" else None
+    for i in range(args.warmup):
         step()
+        if settle and i == 0:
+            torch.cuda.synchronize(dev)
+            settle()
     sync_all()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -391,6 +398,9 @@ def main():
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / max(args.steps, 1) + prepass_ms
 
     failed = False
+    sized = settle() if settle else None
+    if sized and sized["redone"]:
+        raise SystemExit("bench.py: a timed step was sized by a context count that was too small and had to be run again: %r" % (sized,))
     out_bytes = w.output_bytes()
     status_bad = int((w.status != 0).sum().item())
     t_max, total_bytes = reduce_timing(dist if world > 1 else None, elapsed, out_bytes * args.steps, red_dev)
@@ -441,6 +451,8 @@ def main():
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
                          "bins_per_s": w.total_bins / (kernel_ms * 1e-3)},
             "slice_status_errors": status_bad,
+            "sized_by": (None if not sized else {"context_rows_guessed": sized["hint"], "context_rows_needed": sized["rows"],
+                                                 "note": "0 guessed = the step asked the device and waited (no warm-up step before it)"}),
             "prepass_ms_in_step": prepass_ms,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -202,8 +202,10 @@ int avr_multi_load(avr_multi *m, uint64_t *bins_per_device);
  * they wait on `stream` once for that 4-byte count (the chunked forms a second time, for the 4-byte count of slices that
  * need their second pass), i.e. they block the calling thread until the stream has drained up to their census kernel.
  * A caller that must not block uses the batch API (avr_batch_submit sizes the launches by the previous batch's count and
- * checks afterwards) or resolved codes (avr_cabac_encode_resolved_device / _codes_device and every K2 entry: no wait).
- * These are what the batch API is made of and what bench.py times with inputs already resident in HBM.
+ * checks afterwards), the same scheme on its own buffers (avr_cabac_encode_tiles_device_hinted / _chunked_device_hinted below: the
+ * caller passes the count an earlier call reported and looks at what this one reports when it next synchronises), or resolved
+ * codes (avr_cabac_encode_resolved_device / _codes_device and every K2 entry: no wait).
+ * These are what the batch API is made of and what bench.py times with inputs already resident in HBM (its K1 steps: the hinted calls).
  * ONE THREAD PER STREAM: the library keeps a few kilobytes of scratch (and, for the chunked K2, a second stream with its
  * events) per (device, stream); a call's kernels find them there, so two host threads must not enqueue on the same stream
  * at the same time.  What is kept for a batch's own stream is released by avr_batch_destroy.
@@ -287,6 +289,41 @@ int avr_cabac_encode_chunked_device(int device, void *stream,
                                     const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes,
                                     uint8_t *out, const uint64_t *out_off,
                                     uint32_t *out_len, int32_t *status, uint8_t *final_states);
+
+/* The K1 device calls SIZED BY THE CALLER'S GUESS of how many contexts the batch uses (r4) -- the count an earlier call reported,
+ * which is how avr_batch runs from its second batch on -- so that the call enqueues everything and returns: the calls above read
+ * that count back from the device before they can size their launches (avr_cabac_encode_chunked_device: two host round trips a
+ * call, 70 us of config 2's 1.55 ms; the tiles call: one).
+ *   rows_hint  0 = no guess: ask the device and wait, as the calls above do (the counts are reported all the same).
+ *   counts     two words of PINNED host memory, valid once the caller has synchronised `stream`: counts[0] = context rows the
+ *              batch needs, counts[1] = slices left for a second pass (chunked call only: slices with a bin in a context the
+ *              sampled census missed).
+ * What the caller does once it has synchronised.  Tiles call: nothing, it is exact whatever the guess (a slice the guess did not
+ * fit was coded by the call's second launch).  Chunked call: counts[0] > rows_hint -- the outputs are NOT valid: restore `status`
+ * to what it held before the call and call again with rows_hint = 0; else counts[1] > 0 --
+ * avr_cabac_encode_chunked_second_pass_device with the same arguments codes the slices that were left. */
+int avr_cabac_encode_tiles_device_hinted(int device, void *stream,
+                                         const void *tiles, const uint64_t *tile_off,
+                                         const uint32_t *n_bins, const uint32_t *order, size_t n_slices,
+                                         const uint8_t *init_states, size_t n_states,
+                                         uint8_t *out, const uint64_t *out_off,
+                                         uint32_t *out_len, int32_t *status, uint8_t *final_states,
+                                         uint32_t rows_hint, uint32_t *counts);
+int avr_cabac_encode_chunked_device_hinted(int device, void *stream,
+                                           const uint16_t *recs, const uint64_t *rec_off,
+                                           const uint32_t *n_bins, size_t n_slices,
+                                           const uint8_t *init_states, size_t n_states,
+                                           const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes,
+                                           uint8_t *out, const uint64_t *out_off,
+                                           uint32_t *out_len, int32_t *status, uint8_t *final_states,
+                                           uint32_t rows_hint, uint32_t *counts);
+int avr_cabac_encode_chunked_second_pass_device(int device, void *stream,
+                                                const uint16_t *recs, const uint64_t *rec_off,
+                                                const uint32_t *n_bins, size_t n_slices,
+                                                const uint8_t *init_states, size_t n_states,
+                                                const avr_chunk_plan *plan, void *workspace, size_t workspace_bytes,
+                                                uint8_t *out, const uint64_t *out_off,
+                                                uint32_t *out_len, int32_t *status, uint8_t *final_states);
 
 /* K2, intra-slice parallel form ("K2p", avrecode-ms_amd/csrc/avr_k2p.h): the same bytes as avr_range_encode_slices_device for
  * batches of few, long slices.  The range recurrence of arithmetic_code<uint64_t, uint8_t> (recode.cpp:322-323, 823-827) is

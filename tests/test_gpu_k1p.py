@@ -410,6 +410,60 @@ def test_chunked_census_sample_second_pass_and_validation(avr, oracle, stride, h
     assert list(status[good:]) == [avr.SLICE_BAD_RECORD] * 5
 
 
+@pytest.mark.parametrize("stride", [0, 4099])
+def test_device_calls_sized_by_a_guess_of_the_context_count(avr, oracle, hooks, stride):
+    """avr_cabac_encode_chunked_device_hinted / _tiles_device_hinted (what bench.py's steps call): sized by the count a previous run
+    reported nothing waits for the device, and the bytes are the same; the one-lane-per-slice call is exact whatever the guess; the
+    chunked call reports a guess that was too small (counts[0] > rows_hint: run again) and the slices it left for a second pass
+    (stride 4099: the census sees next to nothing, so that is every slice), which avr_cabac_encode_chunked_second_pass_device codes."""
+    import torch
+    if stride:
+        hooks(census_stride=stride)
+    rng = np.random.default_rng(311)
+    ns = 120
+    slices = []
+    for i in range(20):
+        r, s = oracle_lib.random_cabac_stream(rng, 9000 + 1700 * i, 70, terminate=bool(i % 3))
+        slices.append((r, np.concatenate([s, rng.integers(0, 126, ns - 70).astype(np.uint8)])))
+    if stride:                                             # single bins in contexts nobody else uses: the sample misses them
+        for i, ctx in ((2, 119), (7, 100), (9, 71)):
+            slices[i][0][4000 + 777 * i] = np.uint16((ctx << 1) | (i & 1))
+    want = [oracle.cabac_encode(r, s) for r, s in slices]
+
+    def check(w, what):
+        got, status = w.results()
+        fs = w.final_states.cpu().numpy().reshape(len(slices), ns)
+        for i in range(len(slices)):
+            assert status[i] == 0 and got[i] == want[i][0] and fs[i].tobytes() == want[i][1], f"{what}: slice {i}"
+        w.out.zero_(); w.out_len.zero_(); w.final_states.zero_()
+
+    w = avr.DeviceWorkload.from_host(0, [r for r, _ in slices], [s for _, s in slices], 0)
+    # the intra-slice parallel path: no guess, the count's guess, a guess that is too small
+    w.encode_chunked(); torch.cuda.synchronize()
+    first = w.settle()
+    assert first["hint"] == 0 and 60 <= first["rows"] <= 70 and w.rows_hint == min(ns, first["rows"] + 8) and not first["redone"]
+    check(w, "asked")
+    w.encode_chunked(); torch.cuda.synchronize()
+    left = int(w._counts[1])                               # slices the call left for a second pass
+    assert (left >= 1) if stride else (left == 0)
+    second = w.settle()
+    assert second["hint"] == w.rows_hint and second["rows"] == first["rows"] and second["redone"] == bool(left)
+    check(w, "guessed")
+    if not stride:
+        w.rows_hint = 5
+        w.encode_chunked(); torch.cuda.synchronize()
+        assert int(w._counts[0]) == first["rows"] > 5                 # what the caller sees: the outputs are not valid
+        third = w.settle()
+        assert third["redone"] and third["hint"] == 5 and third["rows"] == first["rows"]
+        check(w, "guess too small, run again")
+    # the one-lane-per-slice path: exact whatever the guess (slices the guess did not fit go through its second launch)
+    for guess in (0, 5, ns):
+        w.rows_hint = guess
+        w.encode(); torch.cuda.synchronize()
+        assert not w.settle()["redone"]
+        check(w, f"one lane per slice, guess {guess}")
+
+
 # ------------------------------------------------------------------ K2p: the recoded range coder in three passes
 
 @pytest.mark.parametrize("pass1", ["wave", "lane", "both"])
