@@ -200,6 +200,7 @@ int avr_test_hook_set(const char *name, uint32_t value) {
     else if (!strcmp(name, "k2p_wave")) h.k2p_wave = value;
     else if (!strcmp(name, "k1_waves")) h.k1_waves = value;
     else if (!strcmp(name, "k1_fwd")) h.k1_fwd = value;
+    else if (!strcmp(name, "k1_words8")) h.k1_words8 = value;
     else if (!strcmp(name, "chain_nsegs")) h.chain_nsegs = value;
     else if (!strcmp(name, "chain_whole")) h.chain_whole = value;
     else if (!strcmp(name, "chain_segments")) h.chain_segments = value;

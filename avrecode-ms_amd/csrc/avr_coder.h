@@ -27,8 +27,9 @@ struct ByteWriter {
     uint8_t *base;
     uint32_t n, cap;
     uint64_t acc;           // the last (n & 7) bytes of the stream, most recent in the low byte
+    uint64_t prev;          // PAIR form only: the word before acc's, see put16_even_pair
 
-    __device__ __forceinline__ void init(uint8_t *p, uint32_t capacity) { base = p; n = 0; cap = capacity; acc = 0; }
+    __device__ __forceinline__ void init(uint8_t *p, uint32_t capacity) { base = p; n = 0; cap = capacity; acc = 0; prev = 0; }
 
     __device__ __forceinline__ void store8() {
         if (n <= cap) {
@@ -49,6 +50,32 @@ struct ByteWriter {
         acc = (acc << 16) | (d & 0xffffu);
         n += 2;
         if ((n & 7) == 0) store8();
+    }
+    // PAIR form (k_cabac_encode): the stream's words go out two at a time, 16 bytes a store -- the first of a pair waits in `prev`
+    // (bytes [n & ~15, (n & ~15) + 8) of the stream while n & 8).  drain_pair() ends the form: put8 / store8 / flush take over.
+    __device__ __forceinline__ void put16_even_pair(uint32_t d) {
+        acc = (acc << 16) | (d & 0xffffu);
+        n += 2;
+        if ((n & 7) == 0) {
+            if (n & 8) prev = acc;
+            else if (n <= cap) {
+                uint4 v;
+                v.x = __builtin_bswap32(uint32_t(prev >> 32)); v.y = __builtin_bswap32(uint32_t(prev));
+                v.z = __builtin_bswap32(uint32_t(acc >> 32));  v.w = __builtin_bswap32(uint32_t(acc));
+                *reinterpret_cast<uint4 *>(base + n - 16) = v;
+            } else if (n - 8 <= cap) {
+                uint2 v;
+                v.x = __builtin_bswap32(uint32_t(prev >> 32)); v.y = __builtin_bswap32(uint32_t(prev));
+                *reinterpret_cast<uint2 *>(base + n - 16) = v;
+            }
+        }
+    }
+    __device__ __forceinline__ void drain_pair() {
+        if ((n & 8) && (n & ~7u) <= cap) {
+            uint2 v;
+            v.x = __builtin_bswap32(uint32_t(prev >> 32)); v.y = __builtin_bswap32(uint32_t(prev));
+            *reinterpret_cast<uint2 *>(base + (n & ~15u)) = v;
+        }
     }
     __device__ void flush() {
         const uint32_t r = n & 7;
@@ -84,6 +111,26 @@ struct CabacEncoder {
         }
         uint32_t p = w.n - r;
         if (p > w.cap) return;                          // overflowed output: nothing stored to carry into
+        while (p > 0) {
+            p--;
+            const uint32_t b = uint32_t(w.base[p]) + 1u;
+            w.base[p] = uint8_t(b);
+            if (b <= 0xffu) break;
+        }
+    }
+    __device__ void carry_back_pair() {                 // carry_back() while the writer is in its PAIR form
+        const uint32_t r = w.n & 7;
+        if (r) {
+            const uint64_t mask = (uint64_t(1) << (8 * r)) - 1, v = (w.acc & mask) + 1;
+            w.acc = (w.acc & ~mask) | (v & mask);
+            if ((v >> (8 * r)) == 0) return;
+        }
+        if (w.n & 8) {                                  // the word that waits for its partner
+            w.prev += 1;
+            if (w.prev != 0) return;
+        }
+        uint32_t p = w.n & ~15u;
+        if (p > w.cap) return;
         while (p > 0) {
             p--;
             const uint32_t b = uint32_t(w.base[p]) + 1u;

@@ -46,6 +46,7 @@ struct TestHooks {
     uint32_t local_waves;            // K1p: waves to a workgroup of k_k1p_local (0 = as many waves to a CU as its LDS takes)
     uint32_t chain_nsegs;            // K1p: segments the context chains are cut in (0 = as many as keep the launch in one round of workgroups)
     uint32_t k1_fwd;                 // one-lane-per-slice K1: four state bytes read ahead with forwarding (CabacLaneN::bin4: a measured variant), not one per bin
+    uint32_t k1_words8;              // one-lane-per-slice K1: the output in 8-byte stores (rounds 1-3), not 16-byte ones
     uint32_t k1_waves;               // one-lane-per-slice K1: waves to a workgroup (0 = the built-in count)
     uint32_t k2p_wave;               // K2p pass 1: 1 = a wave per slice, 2 = a lane per slice, 3 = a lane per slice and a wave each for the longest (0 = by slice count)
 };

@@ -181,17 +181,20 @@ struct CabacLaneN {
         const uint32_t k = byp ? bin : 2u * sym;
         return make_uint4(row, sym ? ~0u : 0u, k | next << 24, byp - 23u);
     }
+    template <bool PAIR = false>                                 // PAIR: the output in 16-byte stores (ByteWriter::put16_even_pair)
     __device__ __forceinline__ void digits() {                   // every digit that is due, oldest first
         while (sp >= 15) {
             uint32_t d = uint32_t(L2 >> (sp + 1));
             L2 &= (uint64_t(2) << sp) - 1;
-            if (__builtin_expect(d >> 16, 0)) { e.carry_back(); d &= 0xffffu; }
-            e.w.put16_even(d);
+            if (__builtin_expect(d >> 16, 0)) { if constexpr (PAIR) e.carry_back_pair(); else e.carry_back(); d &= 0xffffu; }
+            if constexpr (PAIR) e.w.put16_even_pair(d); else e.w.put16_even(d);
             sp -= 16;
         }
     }
+    template <bool PAIR = false>
     __device__ void finish() {                                   // back to the reference's (low, range), then its finish()
-        digits();
+        digits<PAIR>();
+        if constexpr (PAIR) e.w.drain_pair();
         const uint32_t ex = uint32_t(15 - sp);                   // 1 .. 22
         uint64_t low = L2 << (ex - 1);
         if (low >= CabacEncoder::kOne) { e.carry_back(); low -= CabacEncoder::kOne; }
@@ -352,7 +355,8 @@ constexpr uint32_t kK1MaxWaves = 16;
 // table / index: the dense renumbering of the batch's contexts (k_k1p_densemap), or null: contexts as the caller
 // numbers them.  n_rows: contexts the kernel keeps states for (dense count, or n_states); init_states / final_states
 // rows are n_states wide, in the caller's numbering.
-// FORM: 1 = normalised form (CabacLaneN: shipped), 0 = the coder as cabac_code.h writes it (CabacLane), 2 = that with its digits
+// FORM: 1 = normalised form (CabacLaneN: shipped; its output in 16-byte stores), 5 = that with 8-byte stores, 4 = with four state bytes read ahead,
+// 0 = the coder as cabac_code.h writes it (CabacLane), 2 = that with its digits
 // staged in LDS (CabacLaneS), 3 = the normalised form with them (CabacLaneNS); 0, 2 and 3 are measured variants of the test build.
 template <bool TILED, int FORM>
 __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
     uint8_t *out, const uint64_t *out_off, uint32_t *out_len, int32_t *status,
     uint8_t *final_states, int32_t want_status) {
     extern __shared__ uint32_t lds[];                            // per wave: state dwords [(n_rows + 4 + 3) / 4][64]; FORM 2: then 16 x 64 staging slots per wave
-    constexpr bool NORM = FORM == 1 || FORM == 3 || FORM == 4;
+    constexpr bool NORM = FORM == 1 || FORM == 3 || FORM == 4 || FORM == 5;           // 5: FORM 1 with 8-byte output stores (rounds 1-3)
     __shared__ uint2 tab[136];                                   // 128 states + pseudo-states 128..135
     __shared__ uint4 tabn[NORM ? 272 : 1];                       // the normalised form's: by (state, bin)
     __shared__ uint32_t sel_off[2048];                           // selector -> byte offset of its state in the lane's column (up to 256 rows of 256 bytes, + 3)
@@ -446,11 +450,11 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
     }
     __syncthreads();
 
-    typename std::conditional<FORM == 3, CabacLaneNS, typename std::conditional<FORM == 1 || FORM == 4, CabacLaneN,
+    typename std::conditional<FORM == 3, CabacLaneNS, typename std::conditional<FORM == 1 || FORM == 4 || FORM == 5, CabacLaneN,
         typename std::conditional<FORM == 2, CabacLaneS, CabacLane>::type>::type>::type L;
     const uint64_t o0 = in_range ? out_off[slice] : 0;
     const uint32_t cap = in_range ? uint32_t(out_off[slice + 1] - o0) : 0;
-    if constexpr (FORM == 1 || FORM == 4) L.init(out + o0, cap);
+    if constexpr (FORM == 1 || FORM == 4 || FORM == 5) L.init(out + o0, cap);
     else if constexpr (FORM == 2 || FORM == 3) L.init(out + o0, cap, lds + (blockDim.x >> 6) * rows4 * 64 + wv * 1024 + lane);
     else L.e.init(0x7F800000u, out + o0, cap);                   // cabac_code.h:30
 
@@ -482,7 +486,8 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
             } else
             if constexpr (NORM) L.bin(rec, offs[k], tabn, st_lane);
             else L.bin(rec, offs[k], tab, st_lane);
-            if constexpr (NORM) { if ((k & 3) == 3) L.digits(); }
+            if constexpr (FORM == 1) { if ((k & 3) == 3) L.template digits<true>(); }
+            else if constexpr (NORM) { if ((k & 3) == 3) L.digits(); }
             if constexpr (FORM == 2 || FORM == 3) { if (k == 7) L.rows(); }
         }
     };
@@ -509,6 +514,7 @@ __global__ __launch_bounds__(64 * kK1MaxWaves) void k_cabac_encode(
         if (active) {
             const bool missed = st_lane[(((n_rows + 3) >> 2) << 8) + ((n_rows + 3) & 3)] == 135u;
             if (after_finish) st = AVR_SLICE_BAD_RECORD;
+            else if constexpr (FORM == 1) L.template finish<true>();
             else if constexpr (FORM != 0) L.finish();
             else L.e.finish();                                   // cabac_code.h:63-65 / ~encoder(), arithmetic_code.h:100
             L.e.w.flush();
@@ -984,9 +990,9 @@ hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, cons
         // since round 3's table entries (avr_k1p.h, CodeEntryC) 31 VALU instructions a bin against the 48 of the form that reads
         // like cabac_code.h, and 2.44 against 2.55 ms per step on config 5.  Test hooks: k1_form_ref = that form (CabacLane),
         // k1_emit_lds = 1: it with the digits staged in LDS (CabacLaneS), 2: the shipped form with them (CabacLaneNS); same bytes all.
-        const int form = test_hooks().k1_emit_lds ? (test_hooks().k1_emit_lds == 2 ? 3 : 2) : test_hooks().k1_form_ref ? 0 : test_hooks().k1_fwd ? 4 : 1;
-        auto kern = tiled ? (form == 4 ? k_cabac_encode<true, 4> : form == 1 ? k_cabac_encode<true, 1> : form == 2 ? k_cabac_encode<true, 2> : form == 3 ? k_cabac_encode<true, 3> : k_cabac_encode<true, 0>)
-                          : (form == 4 ? k_cabac_encode<false, 4> : form == 1 ? k_cabac_encode<false, 1> : form == 2 ? k_cabac_encode<false, 2> : form == 3 ? k_cabac_encode<false, 3> : k_cabac_encode<false, 0>);
+        const int form = test_hooks().k1_emit_lds ? (test_hooks().k1_emit_lds == 2 ? 3 : 2) : test_hooks().k1_form_ref ? 0 : test_hooks().k1_fwd ? 4 : test_hooks().k1_words8 ? 5 : 1;
+        auto kern = tiled ? (form == 5 ? k_cabac_encode<true, 5> : form == 4 ? k_cabac_encode<true, 4> : form == 1 ? k_cabac_encode<true, 1> : form == 2 ? k_cabac_encode<true, 2> : form == 3 ? k_cabac_encode<true, 3> : k_cabac_encode<true, 0>)
+                          : (form == 5 ? k_cabac_encode<false, 5> : form == 4 ? k_cabac_encode<false, 4> : form == 1 ? k_cabac_encode<false, 1> : form == 2 ? k_cabac_encode<false, 2> : form == 3 ? k_cabac_encode<false, 3> : k_cabac_encode<false, 0>);
         if (lds > 48 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
             if (e != hipSuccess) return e;

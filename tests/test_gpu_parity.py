@@ -46,7 +46,14 @@ def pad_states(st, n):
 
 # ------------------------------------------------------------------ golden vectors
 
-def test_cabac_golden_vectors(avr):
+@pytest.mark.parametrize("form", ["shipped", "words8", "fwd"])
+def test_cabac_golden_vectors(avr, hooks, form):
+    """(form: the shipped kernel, its output in 16-byte stores; its measured variants with 8-byte stores and with four state bytes
+    read ahead -- the golden vectors hold the long carry chains)"""
+    if form == "words8":
+        hooks(k1_words8=1)
+    elif form == "fwd":
+        hooks(k1_fwd=1)
     g = np.load(os.path.join(GOLD, "g3_cabac.npz"), allow_pickle=False)
     n = int(g["n_cases"])
     ns = max(len(g[f"states_{i}"]) for i in range(n))
@@ -69,7 +76,7 @@ def test_range_golden_vectors(avr):
 
 # ------------------------------------------------------------------ random, ragged, edge cases
 
-@pytest.mark.parametrize("form", ["ref", "norm", "lds", "ref-lds", "fwd"])
+@pytest.mark.parametrize("form", ["ref", "norm", "lds", "ref-lds", "fwd", "words8"])
 @pytest.mark.parametrize("n_states", [4, 64, 460, 1024])
 def test_cabac_random_ragged(avr, oracle, n_states, form, hooks):
     """form: the one-lane-per-slice coder in normalised form with the digits taken every fourth bin in step across the wave
@@ -80,6 +87,8 @@ def test_cabac_random_ragged(avr, oracle, n_states, form, hooks):
         hooks(k1_emit_lds=2)
     elif form == "fwd":                                      # four state bytes read ahead, an earlier bin of the group forwarding its successor (CabacLaneN::bin4: a measured variant)
         hooks(k1_fwd=1)
+    elif form == "words8":                                   # the output in 8-byte stores (rounds 1-3); shipped: 16-byte ones, two words at a time (ByteWriter::put16_even_pair)
+        hooks(k1_words8=1)
     elif form == "ref-lds":                                  # ... and on the form as the reference writes it (CabacLaneS)
         hooks(k1_emit_lds=1)
     rng = np.random.default_rng(100 + n_states)
