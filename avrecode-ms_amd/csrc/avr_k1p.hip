@@ -428,6 +428,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void k_k1p_ctxchain(Plan p, uint3
         auto four = [&](uint32_t avail) {
 #pragma unroll
             for (uint32_t i = 0; i < 4; i++) {
+                if (i && !__any(left != 0)) break;
                 const uint32_t n = left < 8u ? left : 8u;
                 uint32_t off = (128u << n) - 128u + (avail & ((1u << n) - 1u));         // all of the index that does not wait for the state
                 asm volatile("" : "+v"(off));                                          // (kept whole: the compiler would split it up again)
@@ -510,6 +511,7 @@ __device__ __forceinline__ void chain_step(const uint8_t *tn, const uint32_t *bw
     auto four = [&](uint32_t avail) {
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) {
+            if (i && !__any(left != 0)) break;
             const uint32_t n = left < 8u ? left : 8u;
             uint32_t off = (128u << n) - 128u + (avail & ((1u << n) - 1u));
             asm volatile("" : "+v"(off));
