@@ -111,6 +111,17 @@ class ChunkPlan(ctypes.Structure):
                 ("total_chunks", c_uint32), ("total_blocks", c_uint32)]
 
 
+class ChunkedPart(ctypes.Structure):
+    """avr_chunked_part: one part of avr_cabac_encode_chunked_device_parts (include/avrecode_ms_amd.h)."""
+    _fields_ = [("rec_off", c_void_p), ("n_bins", c_void_p), ("n_slices", c_size_t), ("init_states", c_void_p),
+                ("plan", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+                ("out_off", c_void_p), ("out_len", c_void_p), ("status", c_void_p), ("final_states", c_void_p),
+                ("rows_hint", c_uint32), ("counts", c_void_p)]
+
+
+MAX_PARTS = 8
+
+
 class SynthConfig(ctypes.Structure):
     _fields_ = [("workload", c_int), ("scale_permille", c_uint32), ("seed", c_uint64),
                 ("first_slice", c_uint64), ("n_states", c_uint32)]
@@ -170,6 +181,7 @@ SIGNATURES = {
     "avr_cabac_encode_tiles_device_hinted": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                                      c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                      c_uint32, c_void_p]),
+    "avr_cabac_encode_chunked_device_parts": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t]),
     "avr_range_chunked_workspace_bytes": (c_size_t, [c_size_t, c_void_p, ctypes.c_uint64]),
     "avr_range_encode_chunked_device": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,
                                                 c_void_p, c_void_p, ctypes.c_uint64, c_void_p, c_void_p]),

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <string>
@@ -260,7 +261,7 @@ void avr_batch_destroy(avr_batch *b) {
     b->d_res_off.release(); b->d_dig_off.release(); b->d_chunk_base.release(); b->d_chunk_slice.release();
     b->d_blk_base.release(); b->d_blk_slice.release(); b->d_workspace.release();
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
-    if (b->stream) { avr::forget_stream(b->stream); (void)hipStreamDestroy(b->stream); }
+    if (b->stream) { avr::forget_part_streams(b->stream); avr::forget_stream(b->stream); (void)hipStreamDestroy(b->stream); }
     delete b;
 }
 
@@ -931,6 +932,84 @@ int avr_cabac_encode_tiles_device_hinted(int device, void *stream, const void *t
     const avr::DenseHint hint{std::min<uint32_t>(rows_hint, uint32_t(n_states)), counts, nullptr};
     AVR_HIP(avr::launch_cabac_encode(true, static_cast<hipStream_t>(stream), tiles, tile_off, n_bins, order, uint32_t(n_slices),
                                      init_states, uint32_t(n_states), out, out_off, out_len, status, final_states, AVR_SLICE_OK, true, &hint));
+    return AVR_OK;
+}
+
+extern "C++" {
+// The streams the parts of avr_cabac_encode_chunked_device_parts run on, with their events: one set per (device, caller's stream), made on
+// first use and kept (work on the caller's stream is ordered, so consecutive calls share it); released by avr::forget_part_streams.
+namespace {
+struct PartStreams { int dev; hipStream_t main; hipStream_t side[AVR_MAX_PARTS - 1]; hipEvent_t fork, done[AVR_MAX_PARTS - 1]; };
+std::vector<PartStreams *> g_parts;
+std::mutex g_parts_mu;
+hipError_t part_streams(hipStream_t s, PartStreams **out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_parts_mu);
+    for (PartStreams *x : g_parts)
+        if (x->dev == dev && x->main == s) { *out = x; return hipSuccess; }
+    PartStreams *x = new PartStreams{};
+    x->dev = dev; x->main = s;
+    e = hipEventCreateWithFlags(&x->fork, hipEventDisableTiming);
+    for (int i = 0; i < AVR_MAX_PARTS - 1 && e == hipSuccess; i++) {
+        e = hipStreamCreateWithFlags(&x->side[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&x->done[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) { delete x; return e; }                 // (what was made of it is left to the process's end: an out-of-resources path)
+    g_parts.push_back(x);
+    *out = x;
+    return hipSuccess;
+}
+}  // namespace
+namespace avr {
+void forget_part_streams(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_parts_mu);
+    for (size_t i = 0; i < g_parts.size();) {
+        PartStreams *x = g_parts[i];
+        if (x->main != s) { i++; continue; }
+        for (int k = 0; k < AVR_MAX_PARTS - 1; k++) {
+            (void)hipStreamSynchronize(x->side[k]);
+            avr::forget_stream(x->side[k]);                      // the library's own per-stream scratch of that stream
+            (void)hipEventDestroy(x->done[k]);
+            (void)hipStreamDestroy(x->side[k]);
+        }
+        (void)hipEventDestroy(x->fork);
+        delete x;
+        g_parts.erase(g_parts.begin() + long(i));
+    }
+}
+}  // namespace avr
+}  // extern "C++"
+
+int avr_cabac_encode_chunked_device_parts(int device, void *stream, const uint16_t *recs, size_t n_states, uint8_t *out,
+                                          const avr_chunked_part *parts, size_t n_parts) {
+    if (!parts || n_parts == 0 || n_parts > AVR_MAX_PARTS) return fail(AVR_ERR_INVALID, "1 .. %d parts", AVR_MAX_PARTS);
+    for (size_t i = 0; i < n_parts; i++) {
+        const avr_chunked_part &q = parts[i];
+        if (!q.counts) return fail(AVR_ERR_INVALID, "part %zu: null counts", i);
+        if (int rc = check_chunked(q.rec_off, q.n_bins, q.out_off, q.n_slices, n_states, q.plan, q.workspace, q.workspace_bytes, q.status)) return rc;
+    }
+    if (int rc = select_device(device)) return rc;
+    hipStream_t main = static_cast<hipStream_t>(stream);
+    PartStreams *ps = nullptr;
+    if (n_parts > 1) {
+        AVR_HIP(part_streams(main, &ps));
+        AVR_HIP(hipEventRecord(ps->fork, main));
+    }
+    for (size_t i = 0; i < n_parts; i++) {                       // part 0 on the caller's stream, the others beside it
+        const avr_chunked_part &q = parts[i];
+        hipStream_t s = i == 0 ? main : ps->side[i - 1];
+        if (i) AVR_HIP(hipStreamWaitEvent(s, ps->fork, 0));
+        q.counts[0] = q.counts[1] = 0;
+        if (q.n_slices) {
+            const avr::DenseHint hint{std::min<uint32_t>(q.rows_hint, uint32_t(n_states)), q.counts, q.counts + 1};
+            AVR_HIP(avr::launch_k1p(s, recs, q.rec_off, q.n_bins, uint32_t(q.n_slices), q.init_states, uint32_t(n_states), q.plan,
+                                    q.workspace, out, q.out_off, q.out_len, q.status, q.final_states, &hint));
+        }
+        if (i) AVR_HIP(hipEventRecord(ps->done[i - 1], s));
+    }
+    for (size_t i = 1; i < n_parts; i++) AVR_HIP(hipStreamWaitEvent(main, ps->done[i - 1], 0));
     return AVR_OK;
 }
 

@@ -74,6 +74,7 @@ struct DenseHint { uint32_t rows; uint32_t *host_count; uint32_t *host_retry; };
 
 // what the library keeps per (device, stream) -- the renumbering's scratch, K2p's second stream and events -- released: call before the stream is destroyed
 void forget_stream(hipStream_t s);
+void forget_part_streams(hipStream_t s);                      // avr_api.cpp: the streams of avr_cabac_encode_chunked_device_parts kept for s
 
 hipError_t launch_cabac_encode(bool tiled, hipStream_t s, const void *recs, const uint64_t *off,
                                const uint32_t *n_bins, const uint32_t *order, uint32_t n_slices,

@@ -155,6 +155,22 @@ class DeviceWorkload:
         encode_tiles(self.kind, self.tiles, self.tile_off, self.n_bins, self.order, self.out, self.out_off,
                      self.out_len, self.status, self.init_states, self.n_states, self.final_states, self.device_index)
 
+    def _part_array(self, rows_hint):
+        """avr_chunked_part[n_parts]: the batch's arrays from each part's first slice on, the part's own plan, workspace and counts."""
+        from . import ChunkedPart
+        recs, rec_off = self._slice_major()
+        ns = max(self.n_states, 1)
+        arr = (ChunkedPart * self.n_parts)()
+        for i, p in enumerate(self._parts):
+            a = p["first"]
+            arr[i] = ChunkedPart(
+                rec_off.data_ptr() + 8 * a, self.n_bins.data_ptr() + 4 * a, p["n"], self.init_states.data_ptr() + ns * a,
+                ctypes.addressof(p["plan"]), (p["ws"].data_ptr() + 255) // 256 * 256, p["ws_bytes"],
+                self.out_off.data_ptr() + 8 * a, self.out_len.data_ptr() + 4 * a, self.status.data_ptr() + 4 * a,
+                (self.final_states.data_ptr() + ns * a) if self.final_states is not None else None,
+                rows_hint, self._part_counts.data_ptr() + 8 * i)
+        return arr
+
     def settle(self):
         """After the caller has synchronised the stream of encode() / encode_chunked(): what the device reported about the run that
         was sized by a guess.  Returns {"rows": context rows the batch needs, "hint": what the run was sized by, "redone": ...}.
@@ -163,6 +179,29 @@ class DeviceWorkload:
         import torch
         if self._counts is None or self._hinted_path is None:
             return {"rows": 0, "hint": 0, "redone": False}
+        if self._hinted_path == "parts":                     # what every part reported
+            used, redone = self.rows_hint, False
+            rows = max(int(self._part_counts[2 * i]) for i in range(self.n_parts))
+            if used and rows > used:                         # a part needed more rows than guessed: all of them once more, asking
+                self.status.copy_(self._status_before)
+                self.rows_hint = 0
+                self.encode_chunked()
+                torch.cuda.synchronize(self.n_bins.device)
+                rows, redone = max(int(self._part_counts[2 * i]) for i in range(self.n_parts)), True
+            recs, rec_off = self._slice_major()
+            for i, p in enumerate(self._parts):
+                if int(self._part_counts[2 * i + 1]):        # slices the part left for a second pass
+                    q = self._part_args[i]
+                    _check(lib().avr_cabac_encode_chunked_second_pass_device(
+                        self.device_index, _stream_ptr(torch), recs.data_ptr(), q.rec_off, q.n_bins, q.n_slices, q.init_states,
+                        self.n_states, q.plan, q.workspace, q.workspace_bytes, self.out.data_ptr(), q.out_off, q.out_len, q.status,
+                        q.final_states))
+                    redone = True
+            if redone:
+                torch.cuda.synchronize(self.n_bins.device)
+            if rows:
+                self.rows_hint = min(self.n_states, rows + 8)
+            return {"rows": rows, "hint": used, "redone": redone, "parts": self.n_parts}
         rows, left, used = int(self._counts[0]), int(self._counts[1]), self.rows_hint
         redone = False
         if self._hinted_path == "chunked" and used and rows > used:
@@ -257,6 +296,59 @@ class DeviceWorkload:
                 torch.cuda.synchronize(dev)
         return self.rec_flat, self.rec_off
 
+    def _plan_of(self, a, b):
+        """Plan arrays and workspace of the intra-slice parallel path for slices [a, b), numbered from 0."""
+        import torch
+        from . import CHUNK_BINS, SORT_BLOCK_BINS, ChunkPlan
+        dev = self.n_bins.device
+        nb = self.n_bins[a:b].to(torch.int64)
+        zero = torch.zeros(1, dtype=torch.int64, device=dev)
+        ar = torch.arange(b - a, device=dev)
+        res_off = torch.cat([zero, torch.cumsum((nb + 15) // 16 * 16 + 16, 0)])
+        n_chunks = torch.clamp((nb + CHUNK_BINS - 1) // CHUNK_BINS, min=1)
+        n_blocks = torch.clamp((nb + SORT_BLOCK_BINS - 1) // SORT_BLOCK_BINS, min=1)
+        chunk_base = torch.cat([zero, torch.cumsum(n_chunks, 0)]).to(torch.int32)
+        blk_base = torch.cat([zero, torch.cumsum(n_blocks, 0)]).to(torch.int32)
+        dig_off = torch.cat([zero, torch.cumsum(nb // 2 + 8, 0)])
+        t = dict(res_off=res_off, chunk_base=chunk_base, blk_base=blk_base, dig_off=dig_off,
+                 chunk_slice=torch.repeat_interleave(ar, n_chunks).to(torch.int32),
+                 blk_slice=torch.repeat_interleave(ar, n_blocks).to(torch.int32))
+        plan = ChunkPlan(t["res_off"].data_ptr(), t["chunk_base"].data_ptr(), t["chunk_slice"].data_ptr(),
+                         t["blk_base"].data_ptr(), t["blk_slice"].data_ptr(), t["dig_off"].data_ptr(),
+                         int(res_off[-1]), int(dig_off[-1]), int(chunk_base[-1]), int(blk_base[-1]))
+        p = dict(tensors=t, plan=plan, first=a, n=b - a)
+        if self.kind == KIND_CABAC:
+            ws_bytes = lib().avr_cabac_chunked_workspace_bytes(b - a, self.n_states, ctypes.byref(plan))
+            p.update(ws_bytes=ws_bytes, ws=torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev))
+        return p
+
+    def set_parts(self, n_parts):
+        """The batch through the intra-slice parallel path as n_parts parts of consecutive slices at once, each on a stream of its
+        own (avr_cabac_encode_chunked_device_parts): parts of near-equal chunk counts.  0: by the batch's size -- two parts once the
+        batch is more than one round of workgroups of the path's longest kernel (what the parts fill are the part-empty last rounds:
+        config 2 1.43 -> 1.37 ms in two parts, 1.49 in three; config 4 - 2 %), one part below that (128 slices of config 2: 0.67 ms in
+        one, 0.70 in two)."""
+        import torch
+        from . import CHUNK_BINS, MAX_PARTS
+        nb = self.n_bins.to(torch.int64)
+        chunks = torch.clamp((nb + CHUNK_BINS - 1) // CHUNK_BINS, min=1)
+        total = int(chunks.sum())
+        if n_parts == 0:
+            waves = (total + 63) // 64
+            n_parts = 2 if (waves >= 2048 and self.n_slices >= 64) else 1
+        n_parts = max(1, min(int(n_parts), MAX_PARTS, self.n_slices))
+        self._parts = None
+        self.n_parts = n_parts
+        if n_parts > 1 and self.kind == KIND_CABAC and self._counts is not None:
+            csum = torch.cumsum(chunks, 0).cpu().numpy()
+            import numpy as np
+            cuts = [0] + [int(np.searchsorted(csum, total * (i + 1) / n_parts)) + 1 for i in range(n_parts - 1)] + [self.n_slices]
+            cuts = sorted(set(min(max(c, 0), self.n_slices) for c in cuts))
+            self._parts = [self._plan_of(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+            self.n_parts = len(self._parts)
+            self._part_counts = torch.zeros(2 * self.n_parts, dtype=torch.int32).pin_memory()
+        return self.n_parts
+
     def _chunk_plan(self):
         """Plan arrays and workspace of the intra-slice parallel path (built once, reused)."""
         import torch
@@ -304,6 +396,15 @@ class DeviceWorkload:
                 self.out_len.data_ptr(), self.status.data_ptr()))
             return
         ws_ptr = (p["ws"].data_ptr() + 255) // 256 * 256
+        if self._counts is not None and getattr(self, "_parts", None):
+            self._hinted_path = "parts"
+            if getattr(self, "_status_before", None) is None:
+                self._status_before = self.status.clone()
+            self._part_args = self._part_array(self.rows_hint)
+            _check(lib().avr_cabac_encode_chunked_device_parts(
+                self.device_index, _stream_ptr(torch), recs.data_ptr(), self.n_states, self.out.data_ptr(),
+                ctypes.cast(self._part_args, ctypes.c_void_p), self.n_parts))
+            return
         if self._counts is not None:                         # sized by the previous run's context count: see encode(), settle()
             self._hinted_path = "chunked"
             if getattr(self, "_status_before", None) is None:

@@ -276,6 +276,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--parts", type=int, default=0,
+                    help="the intra-slice parallel K1 path: the batch as this many parts of consecutive slices at once, each on a stream of "
+                         "its own (avr_cabac_encode_chunked_device_parts); 0 = by the batch's size (three for a batch of a few rounds of "
+                         "workgroups, one for a large one), 1 = one call")
     ap.add_argument("--kind", default="cabac", choices=["cabac", "range"])
     ap.add_argument("--slices", type=int, default=0, help="slices per rank (default: the configuration's own count)")
     ap.add_argument("--path", default="auto", choices=["auto", "serial", "chunked"],
@@ -362,6 +366,7 @@ def main():
     if args.full_context_table:
         os.environ["AVR_NO_DENSE"] = "1"
     step = w.encode_chunked if path == "chunked" else w.encode
+    n_parts = w.set_parts(args.parts) if (path == "chunked" and kind == avr.KIND_CABAC and args.records != "resolved") else 1
     if args.records == "resolved":
         if kind != avr.KIND_CABAC:
             raise SystemExit("--records resolved applies to the CABAC kernel")
@@ -451,6 +456,7 @@ def main():
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo,
                          "bins_per_s": w.total_bins / (kernel_ms * 1e-3)},
             "slice_status_errors": status_bad,
+            "parts": n_parts,
             "sized_by": (None if not sized else {"context_rows_guessed": sized["hint"], "context_rows_needed": sized["rows"],
                                                  "note": "0 guessed = the step asked the device and waited (no warm-up step before it)"}),
             "prepass_ms_in_step": prepass_ms,

@@ -325,6 +325,25 @@ int avr_cabac_encode_chunked_second_pass_device(int device, void *stream,
                                                 uint8_t *out, const uint64_t *out_off,
                                                 uint32_t *out_len, int32_t *status, uint8_t *final_states);
 
+/* A batch as several parts at once (r4).  The kernels of the intra-slice parallel path are launched over a part's chunks in rounds of
+ * workgroups, and the last round of each is part empty -- for a batch the size of config 2 (4 736 waves against the 2 048 and 3 072 its
+ * two longest kernels hold at a time) a third of one kernel and half of another.  Slices are independent, so a batch cut into parts of
+ * consecutive slices, each part with a plan and a workspace of its own and run on a stream of its own, fills those rounds with the
+ * other parts' kernels: config 2 in three parts 1.41 -> 1.32 ms.  This call is that: part i is avr_cabac_encode_chunked_device_hinted on
+ * its own arguments (pointers of the whole batch's arrays moved to the part's first slice; rec_off / out_off values stay offsets into
+ * the shared recs / out), on a stream the library keeps for (device, stream); the parts start when `stream` has reached the call and
+ * `stream` continues when all are done.  What the caller does about each part's counts: as for the hinted call. */
+typedef struct {
+    const uint64_t *rec_off;  const uint32_t *n_bins;  size_t n_slices;
+    const uint8_t *init_states;
+    const avr_chunk_plan *plan;  void *workspace;  size_t workspace_bytes;
+    const uint64_t *out_off;  uint32_t *out_len;  int32_t *status;  uint8_t *final_states;
+    uint32_t rows_hint;  uint32_t *counts;
+} avr_chunked_part;
+#define AVR_MAX_PARTS 8
+int avr_cabac_encode_chunked_device_parts(int device, void *stream, const uint16_t *recs, size_t n_states, uint8_t *out,
+                                          const avr_chunked_part *parts, size_t n_parts);
+
 /* K2, intra-slice parallel form ("K2p", avrecode-ms_amd/csrc/avr_k2p.h): the same bytes as avr_range_encode_slices_device for
  * batches of few, long slices.  The range recurrence of arithmetic_code<uint64_t, uint8_t> (recode.cpp:322-323, 823-827) is
  * walked by one lane per slice -- it is exact 63-bit arithmetic on its own previous value and does not decompose --

@@ -464,6 +464,53 @@ def test_device_calls_sized_by_a_guess_of_the_context_count(avr, oracle, hooks, 
         check(w, f"one lane per slice, guess {guess}")
 
 
+@pytest.mark.parametrize("stride", [0, 4099])
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_chunked_batch_as_parts_on_streams_of_their_own(avr, oracle, hooks, parts, stride):
+    """avr_cabac_encode_chunked_device_parts: the batch cut into parts of consecutive slices, each with its own plan, workspace and
+    stream, gives the bytes, final states and statuses of the one call -- asked, sized by the count of the run before, sized too small
+    (every part is run again), and with slices left for a second pass (stride 4099 and single bins in contexts nobody else uses)."""
+    import torch
+    if stride:
+        hooks(census_stride=stride)
+    rng = np.random.default_rng(411 + parts)
+    ns = 150
+    slices = []
+    for i in range(37):
+        r, s = oracle_lib.random_cabac_stream(rng, int(rng.integers(0, 4)) * 5000 + 300 * i, 90, terminate=bool(i % 3))
+        slices.append((r, np.concatenate([s, rng.integers(0, 126, ns - 90).astype(np.uint8)])))
+    if stride:
+        for i, ctx in ((5, 149), (20, 120), (33, 91)):
+            if len(slices[i][0]) > 700:
+                slices[i][0][600 + 7 * i] = np.uint16((ctx << 1) | (i & 1))
+    want = [oracle.cabac_encode(r, s) for r, s in slices]
+    w = avr.DeviceWorkload.from_host(0, [r for r, _ in slices], [s for _, s in slices], 0)
+    assert 2 <= w.set_parts(parts) <= parts
+
+    def check(what):
+        got, status = w.results()
+        fs = w.final_states.cpu().numpy().reshape(len(slices), ns)
+        for i in range(len(slices)):
+            assert status[i] == 0 and got[i] == want[i][0] and fs[i].tobytes() == want[i][1], f"{what}: slice {i}"
+        w.out.zero_(); w.out_len.zero_(); w.final_states.zero_()
+
+    w.encode_chunked(); torch.cuda.synchronize()
+    first = w.settle()
+    assert first["hint"] == 0 and first["parts"] == w.n_parts and not first["redone"]
+    check("asked")
+    w.encode_chunked(); torch.cuda.synchronize()
+    second = w.settle()
+    assert second["hint"] == w.rows_hint and second["rows"] == first["rows"]
+    check("guessed")
+    if not stride:
+        assert not second["redone"]
+        w.rows_hint = 3
+        w.encode_chunked(); torch.cuda.synchronize()
+        third = w.settle()
+        assert third["redone"] and third["hint"] == 3 and third["rows"] == first["rows"]
+        check("guess too small, every part again")
+
+
 # ------------------------------------------------------------------ K2p: the recoded range coder in three passes
 
 @pytest.mark.parametrize("pass1", ["wave", "lane", "both"])
