@@ -1003,7 +1003,7 @@ int avr_cabac_encode_chunked_device_parts(int device, void *stream, const uint16
         if (i) AVR_HIP(hipStreamWaitEvent(s, ps->fork, 0));
         q.counts[0] = q.counts[1] = 0;
         if (q.n_slices) {
-            const avr::DenseHint hint{std::min<uint32_t>(q.rows_hint, uint32_t(n_states)), q.counts, q.counts + 1};
+            const avr::DenseHint hint{std::min<uint32_t>(q.rows_hint, uint32_t(n_states)), q.counts, q.counts + 1, uint32_t(n_parts)};
             AVR_HIP(avr::launch_k1p(s, recs, q.rec_off, q.n_bins, uint32_t(q.n_slices), q.init_states, uint32_t(n_states), q.plan,
                                     q.workspace, out, q.out_off, q.out_len, q.status, q.final_states, &hint));
         }

@@ -70,7 +70,9 @@ inline bool no_hint() { return test_hooks().no_hint || env().no_hint; }
 //   * with a guess the intra-slice parallel path also leaves its second pass (slices with a context the sampled
 //     census missed) to the caller: *host_retry (pinned) gets the number of such slices behind the kernels, and a
 //     caller that finds it non-zero calls launch_k1p_retry with the arguments of launch_k1p.
-struct DenseHint { uint32_t rows; uint32_t *host_count; uint32_t *host_retry; };
+//   * sharing: how many calls like this one are in flight on the device at once (the parts of avr_cabac_encode_chunked_device_parts):
+//     the context chains are cut into as many segments as keep ALL of them in one round of workgroups (0 = 1).
+struct DenseHint { uint32_t rows; uint32_t *host_count; uint32_t *host_retry; uint32_t sharing = 0; };
 
 // what the library keeps per (device, stream) -- the renumbering's scratch, K2p's second stream and events -- released: call before the stream is destroyed
 void forget_stream(hipStream_t s);

@@ -1474,7 +1474,7 @@ static hipError_t launch_resolve(hipStream_t s, Plan p, uint32_t n_slices, const
         const bool few_lanes = uint64_t(n_slices) * n_states <= 49152;
         // segments: as many as keep the launch in one round of workgroups, at least four chunks each on average, at most kMaxChainSegs
         const uint32_t pair_waves = uint32_t((uint64_t(n_slices) * n_states + 63) / 64);
-        uint32_t n_segs = kChainWaveSlots / pair_waves;
+        uint32_t n_segs = kChainWaveSlots / (pair_waves * (hint && hint->sharing ? hint->sharing : 1u));   // (measured with two parts of config 2: 8 / 11 / 12 / 16 segments 1.35 / 1.33 / 1.36 / 1.36 ms)
         n_segs = n_segs > kMaxChainSegs ? kMaxChainSegs : n_segs;
         const uint64_t by_length = uint64_t(pl->total_chunks) / (uint64_t(n_slices) * 4);
         if (n_segs > by_length) n_segs = uint32_t(by_length);
