@@ -76,3 +76,20 @@ def test_one_byte_records_are_refused_where_they_cannot_name_the_contexts(avr):
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "avrecode_ms_amd.h")).read()
     for name, value in (("AVR_SEL8_BYPASS", 126), ("AVR_SEL8_TERMINATE", 127), ("AVR_MAX_STATES8", 126), ("AVR_KIND_CABAC8", 3)):
         assert int(re.search(r"#define\s+%s\s+(\d+)" % name, hdr).group(1)) == value
+
+
+def test_parts_call_checks_its_arguments_before_it_touches_a_device(avr):
+    """avr_cabac_encode_chunked_device_parts: no parts, too many parts, a part without its two words of counts -- refused with
+    AVR_ERR_INVALID and a message, whether or not there is a GPU."""
+    L = avr.lib()
+    ERR_INVALID = -1
+    parts = (avr.ChunkedPart * 2)()
+    assert L.avr_cabac_encode_chunked_device_parts(0, None, None, 64, None, None, 1) < 0
+    assert L.avr_cabac_encode_chunked_device_parts(0, None, None, 64, None, ctypes.cast(parts, ctypes.c_void_p), 0) < 0
+    assert L.avr_cabac_encode_chunked_device_parts(0, None, None, 64, None, ctypes.cast(parts, ctypes.c_void_p), avr.MAX_PARTS + 1) < 0
+    rc = L.avr_cabac_encode_chunked_device_parts(0, None, None, 64, None, ctypes.cast(parts, ctypes.c_void_p), 2)
+    assert rc < 0 and b"counts" in L.avr_last_error()
+    counts = (ctypes.c_uint32 * 4)()
+    assert L.avr_cabac_encode_chunked_device_hinted(0, None, None, None, None, 3, None, 64, None, None, 0, None, None, None, None, None, 0,
+                                                    ctypes.cast(counts, ctypes.c_void_p)) < 0       # null arrays
+    assert L.avr_cabac_encode_tiles_device_hinted(0, None, None, None, None, None, 3, None, 64, None, None, None, None, None, 0, None) < 0   # null counts
