@@ -322,7 +322,7 @@ class DeviceWorkload:
             p.update(ws_bytes=ws_bytes, ws=torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev))
         return p
 
-    def set_parts(self, n_parts):
+    def set_parts(self, n_parts, weights=None):
         """The batch through the intra-slice parallel path as n_parts parts of consecutive slices at once, each on a stream of its
         own (avr_cabac_encode_chunked_device_parts): parts of near-equal chunk counts.  0: by the batch's size -- two parts once the
         batch is more than one round of workgroups of the path's longest kernel (what the parts fill are the part-empty last rounds:
@@ -342,7 +342,9 @@ class DeviceWorkload:
         if n_parts > 1 and self.kind == KIND_CABAC and self._counts is not None:
             csum = torch.cumsum(chunks, 0).cpu().numpy()
             import numpy as np
-            cuts = [0] + [int(np.searchsorted(csum, total * (i + 1) / n_parts)) + 1 for i in range(n_parts - 1)] + [self.n_slices]
+            share = np.cumsum(np.asarray(weights if weights else [1.0] * n_parts, dtype=np.float64))
+            share = share / share[-1]                            # (weights: the parts' shares of the chunks, for experiments; default equal)
+            cuts = [0] + [int(np.searchsorted(csum, total * share[i])) + 1 for i in range(n_parts - 1)] + [self.n_slices]
             cuts = sorted(set(min(max(c, 0), self.n_slices) for c in cuts))
             self._parts = [self._plan_of(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
             self.n_parts = len(self._parts)

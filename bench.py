@@ -276,6 +276,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--part-weights", default="", help="experiments: the parts' shares of the batch's chunks, e.g. 40,60 (default: equal)")
     ap.add_argument("--parts", type=int, default=0,
                     help="the intra-slice parallel K1 path: the batch as this many parts of consecutive slices at once, each on a stream of "
                          "its own (avr_cabac_encode_chunked_device_parts); 0 = by the batch's size (three for a batch of a few rounds of "
@@ -366,7 +367,9 @@ def main():
     if args.full_context_table:
         os.environ["AVR_NO_DENSE"] = "1"
     step = w.encode_chunked if path == "chunked" else w.encode
-    n_parts = w.set_parts(args.parts) if (path == "chunked" and kind == avr.KIND_CABAC and args.records != "resolved") else 1
+    weights = [float(x) for x in args.part_weights.split(",")] if args.part_weights else None
+    n_parts = (w.set_parts(len(weights) if weights else args.parts, weights)
+               if (path == "chunked" and kind == avr.KIND_CABAC and args.records != "resolved") else 1)
     if args.records == "resolved":
         if kind != avr.KIND_CABAC:
             raise SystemExit("--records resolved applies to the CABAC kernel")
